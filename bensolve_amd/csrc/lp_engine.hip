@@ -1,0 +1,737 @@
+// lp_engine.hip -- batched bounded dual simplex on HBM-resident dense tableaux (gfx950).
+//
+// Replaces, for whole batches of right-hand sides, what the reference does one LP at a time
+// through GLPK: lp_set_rows + lp_solve + getters (bslv_lp.c:112-116, 219-259, 261-308) as driven
+// by phase2_primal's loop (bslv_algs.c:1041-1062).
+//
+// Data layout in HBM (one "slot" per LP):
+//   T     (M+1) x ld doubles, row-major, ld = N rounded up to 16 doubles (128-B rows);
+//         rows 0..M-1: x_B = T x_N ; row M: reduced costs d (objective = d . x_N)
+//   beta  M+1 doubles: values of the basic variables, beta[M] = objective value (without shift)
+//   xN    ld doubles: values of the nonbasic variables (padding = 0)
+//   bh[M], nh[N] basis heads (variable ids: 0..M-1 aux, M..M+N-1 structural)
+//   nstat[N] nonbasic status, pos[M+N] (row if basic, -1-col if nonbasic)
+// One lock-step iteration = k_select (one workgroup per LP: leaving row, Harris ratio test,
+// pivot row copied to a side buffer) + k_update (grid = row tiles x LPs: rank-1 update, pure
+// HBM streaming: reads and writes every tableau element once -> 16 B per element per pivot).
+#include "common.h"
+#include <vector>
+#include <algorithm>
+#include <chrono>
+
+namespace bslv {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int NS_L = 0, NS_U = 1, NS_F = 2, NS_S = 3;
+constexpr int ST_RUNNING = -1;
+constexpr int MODE_NONE = 0, MODE_PIVOT = 1, MODE_REFRESH = 2;
+constexpr double TOL_BND = 1e-9, TOL_DJ = 1e-9, TOL_PIV = 1e-9;
+constexpr double BIG = 1e7;   // artificial bound for dual-infeasible free columns
+constexpr int TR = 32;        // tableau rows per workgroup in k_update / k_init
+constexpr int NT = 256;       // threads per workgroup
+
+struct PivDesc { int r, q; double p, pbeta, enter_val; };
+
+struct LpView {
+    int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit;
+    size_t slotT;
+    double *T, *beta, *xN;
+    int *bh, *nh, *nstat, *pos;
+    const double *lb, *ub;
+    const unsigned char *art;   // bit0: lb is artificial, bit1: ub is artificial
+};
+struct BatchView {
+    const int *src, *dst;
+    const double *vlo, *vup;
+    int *status, *iters, *mode, *verified;
+    PivDesc *desc;
+    double *prow;
+};
+
+__device__ __forceinline__ double LO(const LpView &L, const BatchView &Bv, int b, int k)
+{
+    int j = k - L.vfirst;
+    return (j >= 0 && j < L.vcnt) ? Bv.vlo[(size_t)b * L.vcnt + j] : L.lb[k];
+}
+__device__ __forceinline__ double UP(const LpView &L, const BatchView &Bv, int b, int k)
+{
+    int j = k - L.vfirst;
+    return (j >= 0 && j < L.vcnt) ? Bv.vup[(size_t)b * L.vcnt + j] : L.ub[k];
+}
+__device__ __forceinline__ double btol(double bnd) { return TOL_BND * (1.0 + fabs(bnd)); }
+
+// ---- k_prep: copy the small per-slot arrays src -> dst, sanitise nonbasic statuses against the
+//      new bounds and set the nonbasic values (oracle/lp_dense.c sanitize()) ----
+__global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
+{
+    int b = blockIdx.x;
+    if (b >= B) return;
+    int src = Bv.src[b], dst = Bv.dst[b];
+    const int *bh_s = L.bh + (size_t)src * L.M, *nh_s = L.nh + (size_t)src * L.N;
+    const int *ns_s = L.nstat + (size_t)src * L.N, *pos_s = L.pos + (size_t)src * (L.M + L.N);
+    int *bh_d = L.bh + (size_t)dst * L.M, *nh_d = L.nh + (size_t)dst * L.N;
+    int *ns_d = L.nstat + (size_t)dst * L.N, *pos_d = L.pos + (size_t)dst * (L.M + L.N);
+    double *xN_d = L.xN + (size_t)dst * L.ld;
+    const double *drow_s = L.T + (size_t)src * L.slotT + (size_t)L.M * L.ld;
+    if (src != dst) {
+        for (int i = threadIdx.x; i < L.M; i += NT) bh_d[i] = bh_s[i];
+        for (int i = threadIdx.x; i < L.M + L.N; i += NT) pos_d[i] = pos_s[i];
+    }
+    for (int j = threadIdx.x; j < L.ld; j += NT) {
+        if (j >= L.N) { xN_d[j] = 0.0; continue; }
+        int k = nh_s[j];
+        double lo = LO(L, Bv, b, k), up = UP(L, Bv, b, k);
+        int st = ns_s[j];
+        if (lo == up) st = NS_S;
+        else if (isinf(lo) && isinf(up)) st = NS_F;
+        else if (isinf(lo)) st = NS_U;
+        else if (isinf(up)) st = NS_L;
+        else {
+            // boxed: sit at the bound that keeps the reduced cost dual feasible
+            double dj = drow_s[j];
+            if (dj < -TOL_DJ) st = NS_U;
+            else if (dj > TOL_DJ) st = NS_L;
+            else if (st != NS_L && st != NS_U) st = NS_L;
+        }
+        nh_d[j] = k;
+        ns_d[j] = st;
+        xN_d[j] = (st == NS_F) ? 0.0 : (st == NS_U ? up : lo);
+    }
+    if (threadIdx.x == 0) {
+        Bv.status[b] = ST_RUNNING;
+        Bv.iters[b] = 0;
+        Bv.mode[b] = MODE_NONE;
+        Bv.verified[b] = 1;   // k_init recomputes beta from scratch
+    }
+}
+
+// ---- k_init: T_dst = T_src (streamed once) and beta_dst = T . xN_dst, one wave per row ----
+__global__ __launch_bounds__(NT) void k_init(LpView L, BatchView Bv, int B)
+{
+    int b = blockIdx.y;
+    if (b >= B) return;
+    int src = Bv.src[b], dst = Bv.dst[b];
+    const double *Ts = L.T + (size_t)src * L.slotT;
+    double *Td = L.T + (size_t)dst * L.slotT;
+    const double *xN = L.xN + (size_t)dst * L.ld;
+    double *beta = L.beta + (size_t)dst * L.Mp1p;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ld2 = L.ld >> 1;
+    bool copy = (src != dst);
+    for (int rr = wave; rr < TR; rr += NT / WAVE) {
+        int i = blockIdx.x * TR + rr;
+        if (i >= L.Mp1) break;
+        const double2 *s = reinterpret_cast<const double2 *>(Ts + (size_t)i * L.ld);
+        double2 *d = reinterpret_cast<double2 *>(Td + (size_t)i * L.ld);
+        const double2 *x2 = reinterpret_cast<const double2 *>(xN);
+        double acc = 0.0;
+        for (int j2 = lane; j2 < ld2; j2 += WAVE) {
+            double2 v = s[j2];
+            double2 x = x2[j2];
+            if (copy) d[j2] = v;
+            acc = fma(v.x, x.x, acc);
+            acc = fma(v.y, x.y, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) beta[i] = acc;
+    }
+}
+
+// block-wide helpers (NT = 256 = 4 waves)
+__device__ __forceinline__ ValIdx block_argmax(ValIdx x, double *sv, int *si)
+{
+    x = wave_argmax(x);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) { sv[wave] = x.v; si[wave] = x.i; }
+    __syncthreads();
+    ValIdx r{sv[0], si[0]};
+#pragma unroll
+    for (int w = 1; w < NT / WAVE; w++) r = better_max(r, ValIdx{sv[w], si[w]});
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double *sv)
+{
+    v = wave_max(v);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sv[wave] = v;
+    __syncthreads();
+    double r = sv[0];
+#pragma unroll
+    for (int w = 1; w < NT / WAVE; w++) r = fmax(r, sv[w]);
+    return r;
+}
+__device__ __forceinline__ double block_min(double v, double *sv)
+{
+    v = wave_min(v);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sv[wave] = v;
+    __syncthreads();
+    double r = sv[0];
+#pragma unroll
+    for (int w = 1; w < NT / WAVE; w++) r = fmin(r, sv[w]);
+    return r;
+}
+
+// ---- k_select: dual simplex choice of (leaving row r, entering column q) for each running LP.
+//      Same rules as oracle/lp_dense.c dual_simplex(): largest bound violation, Harris two-pass
+//      ratio test with the largest |pivot| among the ties. ----
+__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, int B)
+{
+    __shared__ double sv[NT / WAVE];
+    __shared__ int si[NT / WAVE];
+    int b = blockIdx.x;
+    if (b >= B) return;
+    if (Bv.status[b] != ST_RUNNING) return;
+    const int tid = threadIdx.x;
+    int slot = Bv.dst[b];
+    double *T = L.T + (size_t)slot * L.slotT;
+    double *beta = L.beta + (size_t)slot * L.Mp1p;
+    double *xN = L.xN + (size_t)slot * L.ld;
+    int *bh = L.bh + (size_t)slot * L.M, *nh = L.nh + (size_t)slot * L.N;
+    int *nstat = L.nstat + (size_t)slot * L.N, *pos = L.pos + (size_t)slot * (L.M + L.N);
+    const int M = L.M, N = L.N, ld = L.ld;
+
+    // Phase A: leaving row = largest bound violation; id = 2*i + (below ? 1 : 0)
+    ValIdx best{0.0, -1};
+    for (int i = tid; i < M; i += NT) {
+        int k = bh[i];
+        double lo = LO(L, Bv, b, k), up = UP(L, Bv, b, k), bt = beta[i];
+        if (!isinf(lo)) { double v = lo - bt; if (v > btol(lo)) best = better_max(best, ValIdx{v, 2 * i + 1}); }
+        if (!isinf(up)) { double v = bt - up; if (v > btol(up)) best = better_max(best, ValIdx{v, 2 * i}); }
+    }
+    best = block_argmax(best, sv, si);
+    const double *drow = T + (size_t)M * ld;
+    if (best.i < 0) {
+        if (!Bv.verified[b]) {            // recompute beta from scratch before concluding
+            if (tid == 0) Bv.mode[b] = MODE_REFRESH;
+            return;
+        }
+        // optimal for the bounded problem; unbounded if an artificial bound is active
+        double flag = 0.0;
+        for (int j = tid; j < N; j += NT) {
+            int st = nstat[j];
+            unsigned char a = L.art[nh[j]];
+            if (((st == NS_L && (a & 1)) || (st == NS_U && (a & 2))) && fabs(drow[j]) > TOL_DJ) flag = 1.0;
+        }
+        flag = block_max(flag, sv);
+        if (tid == 0) { Bv.status[b] = flag > 0.0 ? BSLV_LP_UNBOUNDED : BSLV_LP_OPTIMAL; Bv.mode[b] = MODE_NONE; }
+        return;
+    }
+    if (Bv.iters[b] >= L.maxit) {
+        if (tid == 0) { Bv.status[b] = BSLV_LP_UNDEFINED; Bv.mode[b] = MODE_NONE; }
+        return;
+    }
+    const int r = best.i >> 1;
+    const bool below = best.i & 1;
+    const double sgn = below ? 1.0 : -1.0;
+    const double *row = T + (size_t)r * ld;
+
+    // pass 0: row scale for the relative pivot tolerance
+    double rmax = 0.0;
+    for (int j = tid; j < N; j += NT) rmax = fmax(rmax, fabs(row[j]));
+    rmax = block_max(rmax, sv);
+    const double ptol = TOL_PIV * (1.0 + rmax);
+    // pass 1: Harris bound on the dual step
+    double th = INFINITY;
+    for (int j = tid; j < N; j += NT) {
+        int st = nstat[j];
+        if (st == NS_S) continue;
+        double a = sgn * row[j];
+        if (fabs(a) < ptol) continue;
+        if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
+            th = fmin(th, (fabs(drow[j]) + TOL_DJ) / fabs(a));
+    }
+    th = block_min(th, sv);
+    if (isinf(th)) {                      // no entering candidate: primal infeasible
+        if (tid == 0) { Bv.status[b] = BSLV_LP_INFEASIBLE; Bv.mode[b] = MODE_NONE; }
+        return;
+    }
+    // pass 2: largest |pivot| within the bound
+    ValIdx piv{0.0, -1};
+    for (int j = tid; j < N; j += NT) {
+        int st = nstat[j];
+        if (st == NS_S) continue;
+        double a = sgn * row[j];
+        if (fabs(a) < ptol) continue;
+        if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
+            if (fabs(drow[j]) / fabs(a) <= th) piv = better_max(piv, ValIdx{fabs(a), j});
+    }
+    piv = block_argmax(piv, sv, si);
+    const int q = piv.i;
+    // Phase C: publish the pivot row (k_update overwrites row r in place) and the descriptor
+    double *prow = Bv.prow + (size_t)b * ld;
+    for (int j = tid; j < ld; j += NT) prow[j] = (j < N) ? row[j] : 0.0;
+    if (tid == 0) {
+        int kb = bh[r], kn = nh[q];
+        double lo = LO(L, Bv, b, kb), up = UP(L, Bv, b, kb);
+        double target = below ? lo : up;
+        double trq = row[q];
+        double br = beta[r];
+        PivDesc d;
+        d.r = r; d.q = q; d.p = 1.0 / trq;
+        d.pbeta = br - target;
+        d.enter_val = xN[q] + (target - br) / trq;
+        Bv.desc[b] = d;
+        bh[r] = kn; nh[q] = kb;
+        pos[kn] = r; pos[kb] = -1 - q;
+        if (lo == up) { nstat[q] = NS_S; xN[q] = lo; }
+        else if (below) { nstat[q] = NS_L; xN[q] = lo; }
+        else { nstat[q] = NS_U; xN[q] = up; }
+        Bv.mode[b] = MODE_PIVOT;
+        Bv.verified[b] = 0;
+        Bv.iters[b] += 1;
+    }
+}
+
+// ---- k_update: the HBM-bound kernel.  grid = (row tiles, LPs).  For every row i != r:
+//        f = T[i][q] * p ; T[i][j] -= f * prow[j] (j != q) ; T[i][q] = f ; beta[i] -= f * pbeta
+//      row r: T[r][j] = -prow[j] * p (j != q), T[r][q] = p, beta[r] = enter_val.
+//      Row M (reduced costs, objective value) is updated by the same formula.
+//      Algorithmic traffic: one read + one write of the tableau = 16 B per element per pivot. ----
+__global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int B)
+{
+    extern __shared__ double s_prow[];
+    int b = blockIdx.y;
+    if (b >= B) return;
+    if (Bv.status[b] != ST_RUNNING) return;
+    const int mode = Bv.mode[b];
+    if (mode == MODE_NONE) return;
+    int slot = Bv.dst[b];
+    double *T = L.T + (size_t)slot * L.slotT;
+    double *beta = L.beta + (size_t)slot * L.Mp1p;
+    const int ld = L.ld, ld2 = ld >> 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (mode == MODE_REFRESH) {
+        const double2 *x2 = reinterpret_cast<const double2 *>(L.xN + (size_t)slot * ld);
+        for (int rr = wave; rr < TR; rr += NT / WAVE) {
+            int i = blockIdx.x * TR + rr;
+            if (i >= L.Mp1) break;
+            const double2 *t2 = reinterpret_cast<const double2 *>(T + (size_t)i * ld);
+            double acc = 0.0;
+            for (int j2 = lane; j2 < ld2; j2 += WAVE) {
+                double2 v = t2[j2], x = x2[j2];
+                acc = fma(v.x, x.x, acc);
+                acc = fma(v.y, x.y, acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) beta[i] = acc;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) Bv.verified[b] = 1;
+        return;
+    }
+    const PivDesc d = Bv.desc[b];
+    {
+        const double2 *g = reinterpret_cast<const double2 *>(Bv.prow + (size_t)b * ld);
+        double2 *s = reinterpret_cast<double2 *>(s_prow);
+        for (int j2 = threadIdx.x; j2 < ld2; j2 += NT) s[j2] = g[j2];
+    }
+    __syncthreads();
+    const double2 *p2 = reinterpret_cast<const double2 *>(s_prow);
+    const int q2 = d.q >> 1, qodd = d.q & 1;
+    for (int rr = wave; rr < TR; rr += NT / WAVE) {
+        int i = blockIdx.x * TR + rr;
+        if (i >= L.Mp1) break;
+        double2 *t2 = reinterpret_cast<double2 *>(T + (size_t)i * ld);
+        if (i == d.r) {
+            for (int j2 = lane; j2 < ld2; j2 += WAVE) {
+                double2 pr = p2[j2], v;
+                v.x = -pr.x * d.p;
+                v.y = -pr.y * d.p;
+                if (j2 == q2) { if (qodd) v.y = d.p; else v.x = d.p; }
+                t2[j2] = v;
+            }
+            if (lane == 0) beta[i] = d.enter_val;
+            continue;
+        }
+        const double f = T[(size_t)i * ld + d.q] * d.p;
+        if (f == 0.0) continue;           // row untouched by this pivot
+        for (int j2 = lane; j2 < ld2; j2 += WAVE) {
+            double2 v = t2[j2], pr = p2[j2];
+            v.x = fma(-f, pr.x, v.x);
+            v.y = fma(-f, pr.y, v.y);
+            if (j2 == q2) { if (qodd) v.y = f; else v.x = f; }
+            t2[j2] = v;
+        }
+        if (lane == 0) beta[i] = fma(-f, d.pbeta, beta[i]);
+    }
+}
+
+// ---- getters ----
+__global__ void k_get(LpView L, const int *slots, int B, int first, int cnt, int what, double *out)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * cnt) return;
+    int b = idx / cnt, k = first + idx % cnt;
+    int slot = slots[b];
+    int p = L.pos[(size_t)slot * (L.M + L.N) + k];
+    double v;
+    if (what == 0) v = p >= 0 ? L.beta[(size_t)slot * L.Mp1p + p] : L.xN[(size_t)slot * L.ld + (-1 - p)];
+    else v = p >= 0 ? 0.0 : L.T[(size_t)slot * L.slotT + (size_t)L.M * L.ld + (-1 - p)];
+    out[idx] = v;
+}
+__global__ void k_get_obj(LpView L, const int *slots, int B, double c0, double *out)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    out[b] = L.beta[(size_t)slots[b] * L.Mp1p + L.M] + c0;
+}
+__global__ void k_std_heads(LpView L, int slot)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L.M) { L.bh[(size_t)slot * L.M + i] = i; L.pos[(size_t)slot * (L.M + L.N) + i] = i; }
+    if (i < L.N) {
+        L.nh[(size_t)slot * L.N + i] = L.M + i;
+        L.pos[(size_t)slot * (L.M + L.N) + L.M + i] = -1 - i;
+        L.nstat[(size_t)slot * L.N + i] = NS_L;
+    }
+    if (i < L.ld) L.xN[(size_t)slot * L.ld + i] = 0.0;
+    if (i < L.Mp1p) L.beta[(size_t)slot * L.Mp1p + i] = 0.0;
+}
+
+}  // namespace bslv
+
+using namespace bslv;
+
+struct bslv_lpq {
+    LpView L{};
+    int slots = 0;
+    double c0 = 0;
+    hipStream_t stream = nullptr;
+    double *Tstd = nullptr;           // (M+1) x ld image of [A ; cost]
+    double *lb_d = nullptr, *ub_d = nullptr;
+    unsigned char *art_d = nullptr;
+    std::vector<double> cost;         // N+1
+    // batch buffers
+    int Bcap = 0;
+    int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
+    double *vlo_d = nullptr, *vup_d = nullptr, *prow_d = nullptr, *out_d = nullptr;
+    size_t out_cap = 0;
+    PivDesc *desc_d = nullptr;
+    int *status_h = nullptr;          // pinned
+    // stats
+    int last_iters = 0;
+    long last_pivots = 0;
+    double last_update_ms = 0, last_total_ms = 0;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
+};
+
+static int ensure_batch(bslv_lpq *h, int B)
+{
+    if (B <= h->Bcap) return 0;
+    int cap = std::max(B, h->Bcap * 2);
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d);
+    if (h->status_h) (void)hipHostFree(h->status_h);
+    h->Bcap = 0;
+    HIP_TRY(hipMalloc(&h->src_d, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->dst_d, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->status_d, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->iters_d, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->mode_d, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->ver_d, cap * sizeof(int)));
+    size_t vc = (size_t)std::max(1, h->L.vcnt);
+    HIP_TRY(hipMalloc(&h->vlo_d, cap * vc * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->vup_d, cap * vc * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->prow_d, (size_t)cap * h->L.ld * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->desc_d, cap * sizeof(PivDesc)));
+    HIP_TRY(hipHostMalloc(&h->status_h, cap * sizeof(int)));
+    h->Bcap = cap;
+    return 0;
+}
+
+static BatchView bview(bslv_lpq *h)
+{
+    BatchView v;
+    v.src = h->src_d; v.dst = h->dst_d; v.vlo = h->vlo_d; v.vup = h->vup_d;
+    v.status = h->status_d; v.iters = h->iters_d; v.mode = h->mode_d; v.verified = h->ver_d;
+    v.desc = h->desc_d; v.prow = h->prow_d;
+    return v;
+}
+
+static int upload_bounds(bslv_lpq *h, const double *lb, const double *ub)
+{
+    int M = h->L.M, N = h->L.N;
+    std::vector<double> lo(lb, lb + M + N), up(ub, ub + M + N);
+    std::vector<unsigned char> art(M + N, 0);
+    // artificial bounds: a structural column with non-zero cost and no bound on the side its
+    // reduced cost needs would be dual infeasible in the standard basis (oracle: primal phase 1)
+    for (int j = 0; j < N; j++) {
+        double c = h->cost[j + 1];
+        int k = M + j;
+        if (c > 0 && std::isinf(lo[k])) { lo[k] = -BIG; art[k] |= 1; }
+        if (c < 0 && std::isinf(up[k])) { up[k] = BIG; art[k] |= 2; }
+    }
+    HIP_TRY(hipMemcpyAsync(h->lb_d, lo.data(), (M + N) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->ub_d, up.data(), (M + N) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->art_d, art.data(), (M + N), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" {
+
+const char *bslv_last_error(void) { return g_err; }
+
+int bslv_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bslv_device_info(char *name, int name_len, int *cus, size_t *mem_bytes)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (name && name_len > 0) { strncpy(name, p.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    if (cus) *cus = p.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = p.totalGlobalMem;
+    return 0;
+}
+
+int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double *lb, const double *ub,
+                    const double *cost, int var_first, int var_cnt, int pool_slots)
+{
+    if (!out || M < 1 || N < 1 || !A || !lb || !ub || !cost || pool_slots < 1 || var_cnt < 0 ||
+        (var_cnt > 0 && (var_first < 0 || var_first + var_cnt > M + N))) {
+        set_error("bslv_lpq_create: bad argument");
+        return BSLV_E_ARG;
+    }
+    if (bslv_device_count() < 1) { set_error("no HIP device available"); return BSLV_E_NODEVICE; }
+    bslv_lpq *h = new bslv_lpq();
+    LpView &L = h->L;
+    L.M = M; L.N = N;
+    L.ld = (N + 15) / 16 * 16;
+    L.Mp1 = M + 1;
+    L.Mp1p = (M + 1 + 15) / 16 * 16;
+    L.vfirst = var_first; L.vcnt = var_cnt;
+    L.maxit = 50 * (M + N) + 1000;
+    L.slotT = (size_t)L.Mp1 * L.ld;
+    h->slots = pool_slots;
+    h->cost.assign(cost, cost + N + 1);
+    h->c0 = cost[0];
+    int rc = 0;
+    auto fail = [&](int code) { bslv_lpq_destroy(h); return code; };
+    if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
+#define TRYF(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? BSLV_E_NOMEM : BSLV_E_NODEVICE); } } while (0)
+    TRYF(hipMalloc(&L.T, (size_t)pool_slots * L.slotT * sizeof(double)));
+    TRYF(hipMalloc(&L.beta, (size_t)pool_slots * L.Mp1p * sizeof(double)));
+    TRYF(hipMalloc(&L.xN, (size_t)pool_slots * L.ld * sizeof(double)));
+    TRYF(hipMalloc(&L.bh, (size_t)pool_slots * M * sizeof(int)));
+    TRYF(hipMalloc(&L.nh, (size_t)pool_slots * N * sizeof(int)));
+    TRYF(hipMalloc(&L.nstat, (size_t)pool_slots * N * sizeof(int)));
+    TRYF(hipMalloc(&L.pos, (size_t)pool_slots * (M + N) * sizeof(int)));
+    TRYF(hipMalloc(&h->Tstd, L.slotT * sizeof(double)));
+    TRYF(hipMalloc(&h->lb_d, (M + N) * sizeof(double)));
+    TRYF(hipMalloc(&h->ub_d, (M + N) * sizeof(double)));
+    TRYF(hipMalloc(&h->art_d, (M + N)));
+#undef TRYF
+    L.lb = h->lb_d; L.ub = h->ub_d; L.art = h->art_d;
+    {
+        std::vector<double> img(L.slotT, 0.0);
+        for (int i = 0; i < M; i++) memcpy(&img[(size_t)i * L.ld], A + (size_t)i * N, N * sizeof(double));
+        for (int j = 0; j < N; j++) img[(size_t)M * L.ld + j] = cost[j + 1];
+        if (hipMemcpy(h->Tstd, img.data(), L.slotT * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("upload of A failed");
+            return fail(BSLV_E_NODEVICE);
+        }
+    }
+    if ((rc = upload_bounds(h, lb, ub))) return fail(rc);
+    if ((rc = ensure_batch(h, 64))) return fail(rc);
+    *out = h;
+    return 0;
+}
+
+void bslv_lpq_destroy(bslv_lpq *h)
+{
+    if (!h) return;
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
+    fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
+    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d);
+    if (h->status_h) (void)hipHostFree(h->status_h);
+    for (auto &e : h->evpool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int bslv_lpq_pool_slots(const bslv_lpq *h) { return h ? h->slots : 0; }
+size_t bslv_lpq_slot_bytes(const bslv_lpq *h)
+{
+    if (!h) return 0;
+    const LpView &L = h->L;
+    return (L.slotT + L.Mp1p + L.ld) * sizeof(double) + (size_t)(2 * (L.M + L.N) + L.N) * sizeof(int);
+}
+
+int bslv_lpq_set_bounds(bslv_lpq *h, const double *lb, const double *ub)
+{
+    if (!h || !lb || !ub) { set_error("bslv_lpq_set_bounds: bad argument"); return BSLV_E_ARG; }
+    return upload_bounds(h, lb, ub);
+}
+
+int bslv_lpq_set_profile(bslv_lpq *h, int on)
+{
+    if (!h) return BSLV_E_ARG;
+    h->profile = on != 0;
+    return 0;
+}
+
+int bslv_lpq_reset_slot(bslv_lpq *h, int slot)
+{
+    if (!h || slot < 0 || slot >= h->slots) { set_error("bslv_lpq_reset_slot: bad slot %d", slot); return BSLV_E_ARG; }
+    LpView &L = h->L;
+    HIP_TRY(hipMemcpyAsync(L.T + (size_t)slot * L.slotT, h->Tstd, L.slotT * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    int n = std::max(std::max(L.M, L.N), std::max(L.ld, L.Mp1p));
+    hipLaunchKernelGGL(k_std_heads, dim3((n + 255) / 256), dim3(256), 0, h->stream, L, slot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo,
+                         const double *vup, int *status, int *iters)
+{
+    if (!h || B < 0 || (B > 0 && (!src || !dst)) || (B > 0 && h->L.vcnt > 0 && (!vlo || !vup))) {
+        set_error("bslv_lpq_solve_batch: bad argument");
+        return BSLV_E_ARG;
+    }
+    if (B == 0) return 0;
+    for (int b = 0; b < B; b++)
+        if (src[b] < 0 || src[b] >= h->slots || dst[b] < 0 || dst[b] >= h->slots) {
+            set_error("bslv_lpq_solve_batch: slot out of range at %d (src %d dst %d, pool %d)", b, src[b], dst[b], h->slots);
+            return BSLV_E_ARG;
+        }
+    int rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    LpView &L = h->L;
+    if ((size_t)L.ld * sizeof(double) > 64 * 1024) { set_error("row too long for the LDS-staged pivot row (N=%d)", L.N); return BSLV_E_CAPACITY; }
+    auto t0 = std::chrono::steady_clock::now();
+    hipStream_t s = h->stream;
+    HIP_TRY(hipMemcpyAsync(h->src_d, src, B * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->dst_d, dst, B * sizeof(int), hipMemcpyHostToDevice, s));
+    if (L.vcnt > 0) {
+        HIP_TRY(hipMemcpyAsync(h->vlo_d, vlo, (size_t)B * L.vcnt * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->vup_d, vup, (size_t)B * L.vcnt * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    BatchView bv = bview(h);
+    const int tiles = (L.Mp1 + TR - 1) / TR;
+    hipLaunchKernelGGL(k_prep, dim3(B), dim3(NT), 0, s, L, bv, B);
+    hipLaunchKernelGGL(k_init, dim3(tiles, B), dim3(NT), 0, s, L, bv, B);
+    HIP_TRY(hipGetLastError());
+    const size_t lds = (size_t)L.ld * sizeof(double);
+    int it = 0, chunk = 4, running = B;
+    size_t nev = 0;
+    h->last_update_ms = 0;
+    while (running > 0 && it < L.maxit + 8) {
+        for (int c = 0; c < chunk; c++, it++) {
+            hipLaunchKernelGGL(k_select, dim3(B), dim3(NT), 0, s, L, bv, B);
+            if (h->profile) {
+                if (nev == h->evpool.size()) {
+                    hipEvent_t a, b2;
+                    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b2));
+                    h->evpool.emplace_back(a, b2);
+                }
+                HIP_TRY(hipEventRecord(h->evpool[nev].first, s));
+            }
+            hipLaunchKernelGGL(k_update, dim3(tiles, B), dim3(NT), lds, s, L, bv, B);
+            if (h->profile) { HIP_TRY(hipEventRecord(h->evpool[nev].second, s)); nev++; }
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->status_h, h->status_d, B * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        running = 0;
+        for (int b = 0; b < B; b++) running += (h->status_h[b] == ST_RUNNING);
+        if (chunk < 16) chunk *= 2;
+    }
+    if (status) for (int b = 0; b < B; b++) status[b] = h->status_h[b] == ST_RUNNING ? BSLV_LP_UNDEFINED : h->status_h[b];
+    {
+        std::vector<int> itv(B);
+        HIP_TRY(hipMemcpy(itv.data(), h->iters_d, B * sizeof(int), hipMemcpyDeviceToHost));
+        long piv = 0;
+        for (int b = 0; b < B; b++) piv += itv[b];
+        h->last_pivots = piv;
+        if (iters) memcpy(iters, itv.data(), B * sizeof(int));
+    }
+    h->last_iters = it;
+    if (h->profile) {
+        double ms = 0;
+        for (size_t e = 0; e < nev; e++) { float t = 0; (void)hipEventElapsedTime(&t, h->evpool[e].first, h->evpool[e].second); ms += t; }
+        h->last_update_ms = ms;
+    }
+    h->last_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+static int ensure_out(bslv_lpq *h, size_t n)
+{
+    if (n <= h->out_cap) return 0;
+    if (h->out_d) (void)hipFree(h->out_d);
+    h->out_d = nullptr; h->out_cap = 0;
+    HIP_TRY(hipMalloc(&h->out_d, n * sizeof(double)));
+    h->out_cap = n;
+    return 0;
+}
+
+static int get_common(bslv_lpq *h, int B, const int *slot, int first, int cnt, int what, double *out)
+{
+    if (!h || B < 0 || cnt < 0 || !slot || !out || first < 0 || first + cnt > h->L.M + h->L.N) { set_error("bslv_lpq_get: bad argument"); return BSLV_E_ARG; }
+    if (B == 0 || cnt == 0) return 0;
+    for (int b = 0; b < B; b++) if (slot[b] < 0 || slot[b] >= h->slots) { set_error("bslv_lpq_get: bad slot"); return BSLV_E_ARG; }
+    int rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    if ((rc = ensure_out(h, (size_t)B * cnt))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->src_d, slot, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    int n = B * cnt;
+    hipLaunchKernelGGL(k_get, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->L, h->src_d, B, first, cnt, what, h->out_d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->out_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int bslv_lpq_get_primal(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out) { return get_common(h, B, slot, first, cnt, 0, out); }
+int bslv_lpq_get_dual(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out) { return get_common(h, B, slot, first, cnt, 1, out); }
+
+int bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out)
+{
+    if (!h || B < 0 || !slot || !out) { set_error("bslv_lpq_get_obj: bad argument"); return BSLV_E_ARG; }
+    if (B == 0) return 0;
+    for (int b = 0; b < B; b++) if (slot[b] < 0 || slot[b] >= h->slots) { set_error("bslv_lpq_get_obj: bad slot"); return BSLV_E_ARG; }
+    int rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    if ((rc = ensure_out(h, (size_t)B))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->src_d, slot, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_get_obj, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->L, h->src_d, B, h->c0, h->out_d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->out_d, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int bslv_lpq_last_stats(const bslv_lpq *h, int *lockstep_iters, long *pivots, double *update_ms, double *total_ms)
+{
+    if (!h) return BSLV_E_ARG;
+    if (lockstep_iters) *lockstep_iters = h->last_iters;
+    if (pivots) *pivots = h->last_pivots;
+    if (update_ms) *update_ms = h->last_update_ms;
+    if (total_ms) *total_ms = h->last_total_ms;
+    return 0;
+}
+
+}  // extern "C"

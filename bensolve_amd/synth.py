@@ -1,0 +1,93 @@
+"""Deterministic synthetic VLP generators.
+
+PRNG: splitmix64 seeded with the stated seed, u01 = (x >> 11) * 2**-53, values drawn in
+row-major order A, then P (then b where used).  The same stream is reproduced in C by
+bensolve_amd/csrc/host (bslv_synth.c) so files and in-memory data are bit-identical.
+
+  S-small      q=3  n=100  m=200   seed 1   (BASELINE.json configs[1])
+  S-mid        q=5  n=500  m=1000  seed 2   (configs[2], configs[3])
+  S-degenerate q=10 n=2000 m=4000  seed 3   (configs[4])
+"""
+import numpy as np
+
+MASK = (1 << 64) - 1
+
+
+def splitmix64_stream(seed, count):
+    """Return `count` u01 doubles from splitmix64(seed) (vectorised)."""
+    idx = np.arange(1, count + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+
+
+def covering_vlp(m, n, q, seed):
+    """Dense covering-type MOLP: min Px s.t. Ax >= 1, x >= 0, A,P ~ U[0,1).
+
+    Bounded in bensolve's sense (recession cone of the upper image is R^q_+), so phase 2 only
+    ('-b').  Returns dict(A, P, row bounds, col bounds)."""
+    u = splitmix64_stream(seed, m * n + q * n)
+    A = u[: m * n].reshape(m, n)
+    P = u[m * n:].reshape(q, n)
+    return dict(m=m, n=n, q=q, A=A, P=P, optdir=1,
+                rtype=np.full(m, ord("l"), np.uint8), rlb=np.ones(m), rub=np.zeros(m),
+                ctype=np.full(n, ord("l"), np.uint8), clb=np.zeros(n), cub=np.zeros(n))
+
+
+def degenerate_vlp(m, n, q, seed):
+    """Hypercube + integer rows, integer lattice objectives (SURVEY 8d S-degenerate).
+
+    Recipe: A = [I_n ; G], rows 1..n 'd 0 1', G (m-n x n) entries in {0,1,2}, rows 'l 1';
+    P[k][j] in {-2..2}; columns free.  Recorded deviation: the m-n rows of G are 'l 1'
+    cover rows as in the recipe, and the first n rows box x in [0,1]^n, so the upper image is bounded
+    below in every objective (P x is bounded on the cube) and phase 2 alone suffices."""
+    assert m > n
+    g = m - n
+    u = splitmix64_stream(seed, g * n + q * n)
+    G = np.floor(u[: g * n] * 3.0).reshape(g, n)
+    P = (np.floor(u[g * n:] * 5.0) - 2.0).reshape(q, n)
+    A = np.vstack([np.eye(n), G])
+    rtype = np.concatenate([np.full(n, ord("d"), np.uint8), np.full(g, ord("l"), np.uint8)])
+    rlb = np.concatenate([np.zeros(n), np.ones(g)])
+    rub = np.concatenate([np.ones(n), np.zeros(g)])
+    return dict(m=m, n=n, q=q, A=A, P=P, optdir=1, rtype=rtype, rlb=rlb, rub=rub,
+                ctype=np.full(n, ord("f"), np.uint8), clb=np.zeros(n), cub=np.zeros(n))
+
+
+CONFIGS = {
+    "S-small": lambda: covering_vlp(200, 100, 3, 1),
+    "S-mid": lambda: covering_vlp(1000, 500, 5, 2),
+    "S-degenerate": lambda: degenerate_vlp(4000, 2000, 10, 3),
+}
+
+
+def write_vlp(prob, path):
+    """Write `prob` in the reference's .vlp format (bslv_vlp.c:275-588, ex/prob2vlp.m:105-182)
+    with %.17g numbers so that file and in-memory data are bit-identical."""
+    A, P = prob["A"], prob["P"]
+    m, n, q = prob["m"], prob["n"], prob["q"]
+    ai, aj = np.nonzero(A)
+    pi, pj = np.nonzero(P)
+    with open(path, "w") as f:
+        f.write("p vlp %s %d %d %d %d %d\n" % ("min" if prob["optdir"] == 1 else "max", m, n, len(ai), q, len(pi)))
+        f.write("".join("a %d %d %.17g\n" % (i + 1, j + 1, A[i, j]) for i, j in zip(ai, aj)))
+        f.write("".join("o %d %d %.17g\n" % (i + 1, j + 1, P[i, j]) for i, j in zip(pi, pj)))
+        for kind, types, lb, ub, cnt in (("i", prob["rtype"], prob["rlb"], prob["rub"], m),
+                                         ("j", prob["ctype"], prob["clb"], prob["cub"], n)):
+            for k in range(cnt):
+                t = chr(types[k])
+                if t == "f":
+                    if kind == "j":
+                        f.write("%s %d f\n" % (kind, k + 1))
+                elif t == "l":
+                    f.write("%s %d l %.17g\n" % (kind, k + 1, lb[k]))
+                elif t == "u":
+                    f.write("%s %d u %.17g\n" % (kind, k + 1, ub[k]))
+                elif t == "d":
+                    f.write("%s %d d %.17g %.17g\n" % (kind, k + 1, lb[k], ub[k]))
+                elif t == "s":
+                    f.write("%s %d s %.17g\n" % (kind, k + 1, lb[k]))
+        f.write("e\n")

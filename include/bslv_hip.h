@@ -1,0 +1,92 @@
+/*
+ * bslv_hip.h -- C ABI of libbslv_hip.so, the MI355X-native engine behind the two inner loops of
+ * BENSOLVE's Benson outer-approximation algorithm.
+ *
+ * Every entry point is plain C: pointers, sizes, ints.  No torch / HIP types cross the boundary.
+ * All pointers are HOST pointers unless the name ends in _dev.  Return value 0 = success,
+ * non-zero = BSLV_E_* error (bslv_last_error() has the text).  The library never falls back
+ * to a CPU path: if no gfx950 device is usable every constructor fails with BSLV_E_NODEVICE.
+ *
+ * Reference interfaces replaced (file:line relative to the reference tree):
+ *   - bslv_lp.h:27-105   the 17 lp_* functions bslv_algs.o / bslv_main.o import
+ *                        (one global glp_prob, bslv_lp.c:31)            -> section 1 + section 3
+ *   - bslv_poly.h:90-118 the poly__* functions and the polytope / poly_args structs
+ *                        (bslv_poly.h:55-82)                            -> section 2 + section 3
+ *   - bslv_algs.c:958-1161 phase2_primal's inner loop (one vertex -> one LP -> one cut)
+ *                        re-shaped into batch -> kernels -> gather      -> section 4
+ */
+#ifndef BSLV_HIP_H
+#define BSLV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    BSLV_OK = 0,
+    BSLV_E_NODEVICE = 1,   /* no usable HIP device / HIP call failed */
+    BSLV_E_ARG = 2,        /* bad argument */
+    BSLV_E_NOMEM = 3,      /* device or host allocation failed / pool exhausted */
+    BSLV_E_CAPACITY = 4,   /* a fixed-capacity device array overflowed */
+    BSLV_E_STATE = 5       /* call out of order */
+};
+
+/* LP status codes: same numbering as lp_status_type (bslv_lp.h:47). */
+enum { BSLV_LP_INFEASIBLE = 0, BSLV_LP_UNBOUNDED = 1, BSLV_LP_UNEXPECTED = 2, BSLV_LP_UNDEFINED = 3, BSLV_LP_OPTIMAL = 4 };
+
+const char *bslv_last_error(void);
+int bslv_device_count(void);
+/* name / CU count / total global memory of the device the calling thread uses */
+int bslv_device_info(char *name, int name_len, int *cus, size_t *mem_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Batched scalar-LP engine  (replaces lp_solve + getters, bslv_lp.c:219-308, for batches)
+ *
+ * Model (GLPK's, as bslv_lp.c uses it): auxiliary variables r = A x; every variable -- aux
+ * 0..M-1, structural M..M+N-1 -- has bounds [lb,ub] (+-INFINITY allowed); minimise cost.x + c0.
+ * A contiguous range of variables [var_first, var_first+var_cnt) gets PER-LP bounds: these are
+ * the r rows  R_j.y - z <= R_j.v  of P2(v) (bslv_algs.c:637-649,1041-1048).
+ *
+ * State lives in a pool of TABLEAU SLOTS resident in HBM.  A slot holds one LP's dense compact
+ * simplex tableau x_B = T x_N (with reduced-cost row and basic values), so a solved slot is a
+ * warm start for any other right-hand side: every slot that reached optimality is dual feasible
+ * for every v.  solve_batch copies src -> dst, installs the new bounds, and runs the bounded dual
+ * simplex in lock step over the batch.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bslv_lpq bslv_lpq;
+
+int  bslv_lpq_create(bslv_lpq **out, int M, int N,
+                     const double *A /* M*N row-major */,
+                     const double *lb, const double *ub /* M+N each */,
+                     const double *cost /* N+1: cost[0] = constant shift (bslv_lp.h:33) */,
+                     int var_first, int var_cnt, int pool_slots);
+void bslv_lpq_destroy(bslv_lpq *h);
+int  bslv_lpq_pool_slots(const bslv_lpq *h);
+size_t bslv_lpq_slot_bytes(const bslv_lpq *h);
+/* replace the shared bounds (lp_set_rows / lp_set_cols, bslv_lp.c:112-134) */
+int  bslv_lpq_set_bounds(bslv_lpq *h, const double *lb, const double *ub);
+/* put the standard basis (all aux basic; glp_std_basis, bslv_lp.c:101,225) into a slot */
+int  bslv_lpq_reset_slot(bslv_lpq *h, int slot);
+/* Solve B LPs.  LP b starts from slot src[b], works in slot dst[b] (src==dst allowed: in place),
+ * with bounds vlo/vup[b*var_cnt + j] on variable var_first+j.  status[b] gets BSLV_LP_*,
+ * iters[b] the number of dual-simplex pivots.  Any of status/iters may be NULL. */
+int  bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst,
+                          const double *vlo, const double *vup, int *status, int *iters);
+/* getters for solved slots: out[b*cnt + j] = value for variable first+j of slot[b]
+ * (lp_primal_solution_rows/cols, lp_dual_solution_rows/cols, lp_obj_val: bslv_lp.c:261-308) */
+int  bslv_lpq_get_primal(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out);
+int  bslv_lpq_get_dual(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out);
+int  bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out);
+/* statistics of the last solve_batch: lock-step iterations, tableau-update kernel launches,
+ * and the HIP-event time (ms) spent in the tableau-update kernel */
+/* when on, every tableau-update launch is bracketed by HIP events on the engine's stream */
+int  bslv_lpq_set_profile(bslv_lpq *h, int on);
+int  bslv_lpq_last_stats(const bslv_lpq *h, int *lockstep_iters, long *pivots, double *update_ms, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+"""GPU parity: batched dual simplex (HIP, through the C ABI) vs the CPU oracle LP.
+
+Objective values are unique -> compared at 1e-9 relative.  Dual/primal vectors are compared through
+the size-independent LP identities every optimal solution satisfies (strong duality for P2(v):
+z = w.(y - v), c.w = 1, w >= 0, and y - z c <= v componentwise for the default cone)."""
+import numpy as np
+import pytest
+
+from bensolve_amd import synth
+from bensolve_amd.lp import P2Model, LpEngine
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def _random_V(model, prob, rng, B):
+    """points v spread around the image of feasible points (any v gives a feasible, bounded P2(v))"""
+    n = prob["n"]
+    X = rng.random((B, n)) * (3.0 / n) + 1.0 / n
+    Y = X @ prob["P"].T
+    return Y * rng.uniform(0.2, 1.2, size=(B, 1)) + rng.normal(scale=0.05, size=Y.shape)
+
+
+def _check_identities(model, V, obj, w, y):
+    q = model.q
+    assert np.all(w >= -1e-9)
+    np.testing.assert_allclose(w.sum(axis=1), 1.0, rtol=0, atol=1e-9)          # c.w = 1, c = (1..1)
+    np.testing.assert_allclose(np.einsum("bk,bk->b", w, y - V), obj, rtol=1e-8, atol=1e-9)
+    assert np.all(y - obj[:, None] <= V + 1e-8)
+
+
+@pytest.mark.parametrize("m,n,q,seed,B", [(20, 10, 2, 11, 7), (60, 30, 3, 7, 64), (200, 100, 3, 1, 300)])
+def test_batch_matches_oracle(oracle, m, n, q, seed, B):
+    import oracle_api
+    prob = synth.covering_vlp(m, n, q, seed)
+    model = P2Model(prob)
+    rng = np.random.default_rng(seed)
+    V = _random_V(model, prob, rng, B)
+    ub = model.ub_for(V)
+    # --- oracle: sequential warm-started solves (as the reference drives GLPK) ---
+    olp = oracle_api.OracleLP(model.L, model.lo, model.up, model.cost)
+    exp_obj = np.empty(B)
+    for b in range(B):
+        for j in range(model.r):
+            olp.set_bound(model.var_first + j, -np.inf, ub[b, j])
+        assert olp.solve(1) == 4
+        exp_obj[b] = olp.obj()
+    olp.close()
+    # --- engine: cold start in slot 0, then the whole batch warm-started from slot 0 ---
+    eng = LpEngine.from_model(model, pool_slots=B + 1)
+    eng.reset_slot(0)
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+    assert st[0] == 4, "cold start failed"
+    np.testing.assert_allclose(eng.obj([0])[0], exp_obj[0], rtol=RTOL, atol=1e-9)
+    src = np.zeros(B, np.int32)
+    dst = np.arange(1, B + 1, dtype=np.int32)
+    st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+    assert np.all(st == 4)
+    obj = eng.obj(dst)
+    np.testing.assert_allclose(obj, exp_obj, rtol=RTOL, atol=1e-9)
+    w = eng.dual(dst, model.w_first, q)
+    y = eng.primal(dst, model.y_first, q)
+    _check_identities(model, V, obj, w, y)
+    # re-solving in place from the optimal slot needs no pivot and gives the same answer
+    st2, it2 = eng.solve_batch(dst, dst, np.full((B, model.r), -np.inf), ub)
+    assert np.all(st2 == 4) and np.all(it2 == 0)
+    np.testing.assert_allclose(eng.obj(dst), obj, rtol=1e-12, atol=1e-12)
+    eng.close()
+
+
+def test_infeasible_and_unbounded_status():
+    # x1 + x2 >= 2, x <= 0.5 each -> infeasible ; min -x with x free above -> unbounded
+    A = np.array([[1.0, 1.0]])
+    lo = np.array([2.0, 0.0, 0.0]); up = np.array([np.inf, 0.5, 0.5])
+    eng = LpEngine(1, 2, A, lo, up, np.array([0.0, 1.0, 1.0]), 0, 0, 2)
+    eng.reset_slot(0)
+    st, _ = eng.solve_batch([0], [0], np.zeros((1, 0)), np.zeros((1, 0)))
+    assert st[0] == 0
+    eng.close()
+    lo = np.array([-np.inf, 0.0, 0.0]); up = np.array([np.inf, np.inf, np.inf])
+    eng = LpEngine(1, 2, A, lo, up, np.array([0.0, -1.0, 0.0]), 0, 0, 2)
+    eng.reset_slot(0)
+    st, _ = eng.solve_batch([0], [0], np.zeros((1, 0)), np.zeros((1, 0)))
+    assert st[0] == 1
+    eng.close()
