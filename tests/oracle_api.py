@@ -103,3 +103,37 @@ class OracleLP:
         if self.h:
             self.L.olp_free(self.h)
             self.h = None
+
+
+class BensonStats(ctypes.Structure):
+    _fields_ = [("lps", ctypes.c_long), ("cuts", ctypes.c_long), ("pivots", ctypes.c_long),
+                ("new_vertices", ctypes.c_long), ("secs_total", ctypes.c_double), ("secs_lp", ctypes.c_double),
+                ("secs_poly", ctypes.c_double), ("status", ctypes.c_int)]
+
+
+def benson_phase2_primal(prob, R=None, c=None, eps=1e-7, max_lps=0):
+    """Sequential CPU Benson phase 2 (oracle/benson_cpu.c).  Returns (FlatPoly-like dump dict, stats)."""
+    import poly_harness as ph
+    L = load()
+    m, n, q = prob["m"], prob["n"], prob["q"]
+    A = np.ascontiguousarray(prob["A"], np.float64)
+    P = np.ascontiguousarray(prob["P"], np.float64)
+    R = np.eye(q) if R is None else np.ascontiguousarray(R, np.float64)
+    c = np.ones(q) if c is None else np.ascontiguousarray(c, np.float64)
+    r = R.shape[1]
+    f8 = lambda a: np.ascontiguousarray(a, np.float64)
+    rt, ct = np.ascontiguousarray(prob["rtype"], np.uint8), np.ascontiguousarray(prob["ctype"], np.uint8)
+    rlb, rub, clb, cub = f8(prob["rlb"]), f8(prob["rub"]), f8(prob["clb"]), f8(prob["cub"])
+    out = ctypes.c_void_p()
+    st = BensonStats()
+    L.obenson_phase2_primal.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 8 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                                                  ctypes.c_double, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.obenson_phase2_primal(m, n, q, A.ctypes.data, P.ctypes.data, rt.ctypes.data, rlb.ctypes.data, rub.ctypes.data,
+                                 ct.ctypes.data, clb.ctypes.data, cub.ctypes.data, R.ctypes.data, r, c.ctypes.data,
+                                 eps, max_lps, ctypes.byref(out), ctypes.byref(st))
+    fp = ph.FlatPoly.__new__(ph.FlatPoly)
+    fp.L, fp.pre, fp.d, fp.h = L, "opoly_", q, out
+    if not getattr(L, "_poly_bound", False):
+        ph._bind(L, "opoly_")
+        L._poly_bound = True
+    return rc, fp, st
