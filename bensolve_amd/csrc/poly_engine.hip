@@ -1,0 +1,1262 @@
+// poly_engine.hip -- double-description vertex enumeration on the GPU (gfx950).
+//
+// Replaces the polyhedron half of the hot path: poly__add_vrtx / poly__cut / edge_test /
+// poly__intl_apprx / poly__get_vrtx / poly__update_adjacence (bslv_poly.c:104-226, 467-512,
+// 562-787, 992-1010).  One cut = four data-parallel passes with prefix-sum ordering (the same
+// definition as oracle/poly_dd.c, which is checked set-wise against the compiled reference):
+//   K1  k_classify      every live element against hp.y >= alpha  -> PLUS / ZERO / MINUS
+//   E   k_edge_flags / k_edge_emit   MINUS-PLUS edges create vertices, survivors are compacted
+//   Z   k_vert_flags / k_vert_emit   ZERO elements join the new facet (incidence rebuilt)
+//   K2  k_pair_flags / k_pair_emit   adjacency prune over all pairs of the new facet:
+//       sorted-list intersection prefilter (|inc_i & inc_j| >= d-1) per lane, then a wave-
+//       cooperative superset scan (ballot over the facet's members) for the surviving pairs.
+// HBM layout: coordinates SoA X[k*cap + i] (coalesced K1 loads), flags 1 B/element, incidence as
+// sorted facet-id lists in one pool (inc_off/inc_len), edges as int2 pairs (ping-pong buffers).
+#include "common.h"
+#include <vector>
+#include <algorithm>
+#include <cmath>
+
+namespace bslv {
+
+constexpr int MAXD = 16;
+constexpr double POLY_EPS = 1e-9;      // bslv_poly.h:47
+constexpr int PB = 256;                // threads per workgroup in the poly kernels
+constexpr unsigned char F_USED = 1, F_IDEAL = 2, F_SLTN = 4;
+
+struct Hp { double h[MAXD + 1]; };
+struct Tri { int a, b, c; };
+
+struct PolyView {
+    int d, cap;
+    double *X;              // d x cap
+    unsigned char *flag;    // cap
+    signed char *cls;       // cap
+    unsigned *inc_off;      // cap
+    int *inc_len;           // cap
+    int *pool;              // poolcap
+    unsigned char *keep;    // poolcap (all zero between cuts)
+};
+
+// ---------------- scans ----------------
+__device__ __forceinline__ Tri tri_add(Tri x, Tri y) { return Tri{x.a + y.a, x.b + y.b, x.c + y.c}; }
+__device__ __forceinline__ Tri tri_shfl_up(Tri x, int o)
+{
+    return Tri{__shfl_up(x.a, o, WAVE), __shfl_up(x.b, o, WAVE), __shfl_up(x.c, o, WAVE)};
+}
+// exclusive scan over the workgroup (blockDim.x multiple of 64, <= 1024); total returned in *tot
+__device__ Tri block_exscan(Tri v, Tri *tot, Tri *lds /* >= 16 */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    Tri inc = v;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        Tri y = tri_shfl_up(inc, o);
+        if (lane >= o) inc = tri_add(inc, y);
+    }
+    __syncthreads();
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    Tri base{0, 0, 0}, total{0, 0, 0};
+    for (int w = 0; w < nw; w++) {
+        if (w < wave) base = tri_add(base, lds[w]);
+        total = tri_add(total, lds[w]);
+    }
+    *tot = total;
+    Tri ex = tri_add(base, inc);
+    ex.a -= v.a; ex.b -= v.b; ex.c -= v.c;
+    return ex;
+}
+// scan of per-block sums by one workgroup; sums[] becomes exclusive prefixes, totals[0] the grand total
+__global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *totals)
+{
+    __shared__ Tri lds[16];
+    Tri carry{0, 0, 0};
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        Tri v = i < nb ? sums[i] : Tri{0, 0, 0};
+        Tri tot;
+        Tri ex = block_exscan(v, &tot, lds);
+        if (i < nb) sums[i] = tri_add(ex, carry);
+        carry = tri_add(carry, tot);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[0] = carry;
+}
+
+// ---------------- K1: classify ----------------
+__device__ __forceinline__ signed char classify_one(const PolyView &P, const Hp &hp, int i, unsigned char fl)
+{
+    double s = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < P.d; k++) s = fma(hp.h[k], P.X[(size_t)k * P.cap + i], s);
+    double a = (fl & F_IDEAL) ? 0.0 : hp.h[P.d];
+    return (s > a + POLY_EPS) ? 1 : (s > a - POLY_EPS ? 0 : -1);
+}
+// counters[0] = #MINUS, counters[1] = #ZERO
+__global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters)
+{
+    int i = blockIdx.x * PB + threadIdx.x;
+    int isminus = 0, iszero = 0;
+    if (i < nv) {
+        unsigned char fl = P.flag[i];
+        signed char c = 2;
+        if (fl & F_USED) { c = classify_one(P, hp, i, fl); isminus = c < 0; iszero = c == 0; }
+        P.cls[i] = c;
+    }
+    unsigned long long bm = __ballot(isminus), bz = __ballot(iszero);
+    if ((threadIdx.x & 63) == 0) {
+        if (bm) atomicAdd(&counters[0], __popcll(bm));
+        if (bz) atomicAdd(&counters[1], __popcll(bz));
+    }
+}
+
+// Batched incidence kernel: classes of nv elements against B halfspaces, 2 bits
+// each (0 dead, 1 MINUS, 2 ZERO, 3 PLUS), 32 halfspaces per 64-bit word, out[w*cap + i];
+// anyminus[b] != 0 iff some live element violates halfspace b.  Algorithmic bytes:
+// 8 d nv (coords) + nv (flags) + 8 (d+1) B (halfspaces) + nv B / 4 (classes).
+__global__ __launch_bounds__(PB) void k_classify_batch(PolyView P, const double *hps /* B x (d+1) */, int B, int nv,
+                                                       unsigned long long *out, int *anyminus)
+{
+    extern __shared__ double s_hp[];
+    const int d = P.d;
+    for (int t = threadIdx.x; t < B * (d + 1); t += PB) s_hp[t] = hps[t];
+    __syncthreads();
+    int i = blockIdx.x * PB + threadIdx.x;
+    bool live = false, ideal = false;
+    double x[MAXD];
+    if (i < nv) {
+        unsigned char fl = P.flag[i];
+        live = fl & F_USED; ideal = fl & F_IDEAL;
+#pragma unroll
+        for (int k = 0; k < MAXD; k++) x[k] = k < d ? P.X[(size_t)k * P.cap + i] : 0.0;
+    }
+    const int nw = (B + 31) / 32;
+    for (int w = 0; w < nw; w++) {
+        unsigned long long word = 0;
+        for (int bb = 0; bb < 32; bb++) {
+            int b = w * 32 + bb;
+            if (b >= B) break;
+            const double *h = s_hp + b * (d + 1);
+            double s = 0.0;
+            for (int k = 0; k < d; k++) s = fma(h[k], x[k], s);
+            double a = ideal ? 0.0 : h[d];
+            unsigned long long c = !live ? 0ull : (s > a + POLY_EPS ? 3ull : (s > a - POLY_EPS ? 2ull : 1ull));
+            word |= c << (2 * bb);
+            unsigned long long anym = __ballot(c == 1ull);
+            if (anym && (threadIdx.x & 63) == 0) anyminus[b] = 1;   // benign race: all write 1
+        }
+        if (i < nv) out[(size_t)w * P.cap + i] = word;
+    }
+}
+
+// ---------------- sorted-list helpers ----------------
+__device__ __forceinline__ int isect_count(const int *a, int na, const int *b, int nb)
+{
+    int i = 0, j = 0, n = 0;
+    while (i < na && j < nb) {
+        int x = a[i], y = b[j];
+        n += (x == y);
+        i += (x <= y);
+        j += (y <= x);
+    }
+    return n;
+}
+__device__ __forceinline__ int isect3_count(const int *a, int na, const int *b, int nb, const int *c, int nc)
+{
+    int i = 0, j = 0, k = 0, n = 0;
+    while (i < na && j < nb && k < nc) {
+        int x = a[i], y = b[j], z = c[k];
+        int m = max(x, max(y, z));
+        if (x == m && y == m && z == m) { n++; i++; j++; k++; }
+        else { i += (x < m); j += (y < m); k += (z < m); }
+    }
+    return n;
+}
+
+// ---------------- E: edges ----------------
+// eflag: 0 dropped, 1 survives, 2 crossing with a MINUS (b PLUS), 3 crossing with b MINUS
+// per element triple: (survive, cross, new incidence-list length)
+__device__ __forceinline__ Tri edge_triple(const PolyView &P, const int2 e, unsigned char *fl)
+{
+    signed char ca = P.cls[e.x], cb = P.cls[e.y];
+    Tri t{0, 0, 0};
+    unsigned char f = 0;
+    if ((ca == -1 && cb == 1) || (ca == 1 && cb == -1)) {
+        f = (ca == -1) ? 2 : 3;
+        t.b = 1;
+        t.c = isect_count(P.pool + P.inc_off[e.x], P.inc_len[e.x], P.pool + P.inc_off[e.y], P.inc_len[e.y]) + 1;
+    } else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = 1; t.a = 1; }
+    *fl = f;
+    return t;
+}
+__global__ __launch_bounds__(PB) void k_edge_flags(PolyView P, const int2 *E, int ne, unsigned char *eflag, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    int e = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (e < ne) { unsigned char f; t = edge_triple(P, E[e], &f); eflag[e] = f; }
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+// writes survivors to Enew[0..nsurv), creates vertex nv0+crossidx with its incidence list at
+// pool[pool0 + off), its edge at Enew[nsurv + crossidx], and marks keep[] for ZERO-PLUS edges
+__global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, const int2 *E, int ne, const unsigned char *eflag,
+                                                   const Tri *bpre, const Tri *totals, int2 *Enew, int nv0, unsigned pool0)
+{
+    __shared__ Tri lds[16];
+    int e = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    unsigned char f = 0;
+    int2 ed{0, 0};
+    if (e < ne) {
+        f = eflag[e]; ed = E[e];
+        if (f == 1) t.a = 1;
+        else if (f >= 2) {
+            t.b = 1;
+            t.c = isect_count(P.pool + P.inc_off[ed.x], P.inc_len[ed.x], P.pool + P.inc_off[ed.y], P.inc_len[ed.y]) + 1;
+        }
+    }
+    Tri tot;
+    Tri ex = block_exscan(t, &tot, lds);
+    if (e >= ne) return;
+    ex = tri_add(ex, bpre[blockIdx.x]);
+    const int d = P.d;
+    if (f == 1) {
+        Enew[ex.a] = ed;
+        // ZERO element keeps the facets it shares with a PLUS neighbour (bslv_poly.c:634-652)
+        signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
+        int z = -1, pl = -1;
+        if (ca == 0 && cb == 1) { z = ed.x; pl = ed.y; }
+        else if (ca == 1 && cb == 0) { z = ed.y; pl = ed.x; }
+        if (z >= 0) {
+            const int *A = P.pool + P.inc_off[z], *Bp = P.pool + P.inc_off[pl];
+            unsigned char *K = P.keep + P.inc_off[z];
+            int na = P.inc_len[z], nb = P.inc_len[pl], i = 0, j = 0;
+            while (i < na && j < nb) {
+                int x = A[i], y = Bp[j];
+                if (x == y) K[i] = 1;
+                i += (x <= y);
+                j += (y <= x);
+            }
+        }
+    } else if (f >= 2) {
+        const int mi = (f == 2) ? ed.x : ed.y, pl = (f == 2) ? ed.y : ed.x;
+        const int w = nv0 + ex.b;
+        const bool im = P.flag[mi] & F_IDEAL, ip = P.flag[pl] & F_IDEAL;
+        double xm[MAXD], xp[MAXD];
+        for (int k = 0; k < d; k++) { xm[k] = P.X[(size_t)k * P.cap + mi]; xp[k] = P.X[(size_t)k * P.cap + pl]; }
+        double hb = 0.0, hd = 0.0, a2 = hp.h[d];
+        unsigned char nf = F_USED;
+        // new vertex on the edge (bslv_poly.c:597-627); same operation order as oracle/poly_dd.c
+        if (ip && im) {
+            a2 = 0.0;
+            for (int k = 0; k < d; k++) hd = fma(hp.h[k], xp[k] - xm[k], hd);
+            for (int k = 0; k < d; k++) hb = fma(hp.h[k], xm[k], hb);
+            double mu = (a2 - hb) / hd;
+            for (int k = 0; k < d; k++) P.X[(size_t)k * P.cap + w] = fma(mu, xp[k] - xm[k], xm[k]);
+            nf |= F_IDEAL;
+        } else if (!ip && !im) {
+            for (int k = 0; k < d; k++) hd = fma(hp.h[k], xm[k] - xp[k], hd);
+            for (int k = 0; k < d; k++) hb = fma(hp.h[k], xp[k], hb);
+            double mu = (a2 - hb) / hd;
+            for (int k = 0; k < d; k++) P.X[(size_t)k * P.cap + w] = fma(mu, xm[k] - xp[k], xp[k]);
+        } else {
+            const double *base = ip ? xm : xp, *dirv = ip ? xp : xm;
+            for (int k = 0; k < d; k++) hd = fma(hp.h[k], dirv[k], hd);
+            for (int k = 0; k < d; k++) hb = fma(hp.h[k], base[k], hb);
+            double mu = (a2 - hb) / hd;
+            for (int k = 0; k < d; k++) P.X[(size_t)k * P.cap + w] = fma(mu, dirv[k], base[k]);
+        }
+        P.flag[w] = nf;
+        P.cls[w] = 0;
+        // incidence = inc(minus) & inc(plus) + new facet (bslv_poly.c:634-665)
+        const unsigned off = pool0 + (unsigned)ex.c;
+        int *out = P.pool + off;
+        const int *A = P.pool + P.inc_off[mi], *Bp = P.pool + P.inc_off[pl];
+        int na = P.inc_len[mi], nb = P.inc_len[pl], i = 0, j = 0, n = 0;
+        while (i < na && j < nb) {
+            int x = A[i], y = Bp[j];
+            if (x == y) out[n++] = x;
+            i += (x <= y);
+            j += (y <= x);
+        }
+        out[n++] = facet;
+        P.inc_off[w] = off;
+        P.inc_len[w] = n;
+        Enew[totals[0].a + ex.b] = int2{w, pl};
+    }
+}
+
+// ---------------- Z: on-plane elements ----------------
+// triple: (is ZERO, 0, new list length = kept + 1)
+__global__ __launch_bounds__(PB) void k_vert_flags(PolyView P, int nv0, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    int i = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (i < nv0 && P.cls[i] == 0) {
+        const unsigned char *K = P.keep + P.inc_off[i];
+        int n = P.inc_len[i], kept = 0;
+        for (int j = 0; j < n; j++) kept += K[j];
+        t.a = 1; t.c = kept + 1;
+    }
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_vert_emit(PolyView P, int facet, int nv0, const Tri *bpre, int *members, unsigned pool0)
+{
+    __shared__ Tri lds[16];
+    int i = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    signed char c = 2;
+    if (i < nv0) {
+        c = P.cls[i];
+        if (c == 0) {
+            const unsigned char *K = P.keep + P.inc_off[i];
+            int n = P.inc_len[i], kept = 0;
+            for (int j = 0; j < n; j++) kept += K[j];
+            t.a = 1; t.c = kept + 1;
+        }
+    }
+    Tri tot;
+    Tri ex = block_exscan(t, &tot, lds);
+    if (i >= nv0) return;
+    if (c == -1) { P.flag[i] &= ~F_USED; return; }
+    if (c != 0) return;
+    ex = tri_add(ex, bpre[blockIdx.x]);
+    members[ex.a] = i;
+    const unsigned off_old = P.inc_off[i], off_new = pool0 + (unsigned)ex.c;
+    const int n = P.inc_len[i];
+    int m = 0;
+    for (int j = 0; j < n; j++)
+        if (P.keep[off_old + j]) { P.pool[off_new + m++] = P.pool[off_old + j]; P.keep[off_old + j] = 0; }
+    P.pool[off_new + m++] = facet;
+    P.inc_off[i] = off_new;
+    P.inc_len[i] = m;
+}
+__global__ void k_iota_members(int *members, int nzero, int nv0, int ncross)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ncross) members[nzero + k] = nv0 + k;
+}
+
+// ---------------- K2: adjacency prune over the members of the new facet ----------------
+// grid.x enumerates (row i, chunk of 256 columns j > i) in lexicographic order via rowblk[]:
+// block g handles row rowof[g], columns j0[g] .. j0[g]+255.
+struct PairBlk { int i, j0; };
+__global__ __launch_bounds__(PB) void k_pair_flags(PolyView P, const int *members, int nm, const PairBlk *blks,
+                                                    unsigned char *pflag, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    __shared__ int s_row[1024];
+    const PairBlk pb = blks[blockIdx.x];
+    const int vi = members[pb.i];
+    const int ni = P.inc_len[vi];
+    const int *Li = P.pool + P.inc_off[vi];
+    const bool cached = ni <= 1024;
+    if (cached) for (int t = threadIdx.x; t < ni; t += PB) s_row[t] = Li[t];
+    __syncthreads();
+    const int *A = cached ? s_row : Li;
+    const int j = pb.j0 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int vj = -1, nj = 0, nmut = 0;
+    const int *Lj = nullptr;
+    bool cand = false;
+    if (j < nm) {
+        vj = members[j];
+        nj = P.inc_len[vj];
+        Lj = P.pool + P.inc_off[vj];
+        nmut = isect_count(A, ni, Lj, nj);
+        cand = (P.d == 1) || (nmut >= P.d - 1);        // edge_test, bslv_poly.c:482-485
+    }
+    // wave-cooperative superset scan: for each candidate pair of this wave, all 64 lanes sweep the
+    // members w and test  |inc_i & inc_j & inc_w| == |inc_i & inc_j|  (bslv_poly.c:487-505)
+    bool adj = cand;
+    unsigned long long todo = __ballot(cand && P.d > 1);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int cj = __shfl(vj, src, WAVE);
+        const int cn = __shfl(nmut, src, WAVE);
+        const int cnj = P.inc_len[cj];
+        const int *cL = P.pool + P.inc_off[cj];
+        bool found = false;
+        for (int base = 0; base < nm; base += WAVE) {
+            int w = base + lane;
+            bool hit = false;
+            if (w < nm) {
+                int vw = members[w];
+                if (vw != vi && vw != cj) {
+                    int nw_ = P.inc_len[vw];
+                    if (nw_ >= cn) hit = isect3_count(A, ni, cL, cnj, P.pool + P.inc_off[vw], nw_) == cn;
+                }
+            }
+            if (__ballot(hit)) { found = true; break; }
+        }
+        if (lane == src) adj = !found;
+    }
+    Tri t{adj ? 1 : 0, 0, 0};
+    pflag[(size_t)blockIdx.x * PB + threadIdx.x] = adj ? 1 : 0;
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_pair_emit(const int *members, const PairBlk *blks, const unsigned char *pflag,
+                                                   const Tri *bpre, int2 *E, int ebase)
+{
+    __shared__ Tri lds[16];
+    const PairBlk pb = blks[blockIdx.x];
+    unsigned char f = pflag[(size_t)blockIdx.x * PB + threadIdx.x];
+    Tri t{f, 0, 0};
+    Tri tot;
+    Tri ex = block_exscan(t, &tot, lds);
+    if (!f) return;
+    E[ebase + bpre[blockIdx.x].a + ex.a] = int2{members[pb.i], members[pb.j0 + threadIdx.x]};
+}
+
+// unprocessed = used && !sltn (bslv_poly.c:214-216): triple (flag, 0, 0)
+__global__ __launch_bounds__(PB) void k_unproc_flags(PolyView P, int nv, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    int i = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (i < nv) { unsigned char fl = P.flag[i]; t.a = (fl & F_USED) && !(fl & F_SLTN); }
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_unproc_emit(PolyView P, int nv, const Tri *bpre, int maxout, int *idx, double *val, unsigned char *fl_out)
+{
+    __shared__ Tri lds[16];
+    int i = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    unsigned char fl = 0;
+    if (i < nv) { fl = P.flag[i]; t.a = (fl & F_USED) && !(fl & F_SLTN); }
+    Tri tot;
+    Tri ex = block_exscan(t, &tot, lds);
+    if (i >= nv || !t.a) return;
+    int pos = bpre[blockIdx.x].a + ex.a;
+    if (pos >= maxout) return;
+    idx[pos] = i;
+    fl_out[pos] = fl;
+    for (int k = 0; k < P.d; k++) val[(size_t)pos * P.d + k] = P.X[(size_t)k * P.cap + i];
+}
+__global__ void k_mark(PolyView P, const int *idx, int n, unsigned char bit)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) P.flag[idx[k]] |= bit;
+}
+
+// ---------------- dual-side adjacency (poly__update_adjacence on the dual, bslv_poly.c:992-1010) ----------------
+// items = live facets, lists = vertices on the facet (sorted); candidate pool of a pair = facets
+// through its first mutual vertex (bslv_poly.c:487-491)
+struct DualView {
+    const int *ids;          // live facet ids, ascending
+    const unsigned *foff;    // per facet id
+    const int *flen;
+    const int *fpool;        // vertex ids
+    const unsigned char *flive;
+};
+__device__ __forceinline__ int isect_count_first(const int *a, int na, const int *b, int nb, int *first)
+{
+    int i = 0, j = 0, n = 0, f = -1;
+    while (i < na && j < nb) {
+        int x = a[i], y = b[j];
+        if (x == y) { if (n == 0) f = x; n++; }
+        i += (x <= y);
+        j += (y <= x);
+    }
+    *first = f;
+    return n;
+}
+__global__ __launch_bounds__(PB) void k_dpair_flags(PolyView P, DualView D, int nm, const PairBlk *blks, unsigned char *pflag, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    __shared__ int s_row[1024];
+    const PairBlk pb = blks[blockIdx.x];
+    const int fi = D.ids[pb.i];
+    const int ni = D.flen[fi];
+    const int *Li = D.fpool + D.foff[fi];
+    const bool cached = ni <= 1024;
+    if (cached) for (int t = threadIdx.x; t < ni; t += PB) s_row[t] = Li[t];
+    __syncthreads();
+    const int *A = cached ? s_row : Li;
+    const int j = pb.j0 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int fj = -1, nmut = 0, first = -1;
+    bool cand = false;
+    if (j < nm) {
+        fj = D.ids[j];
+        nmut = isect_count_first(A, ni, D.fpool + D.foff[fj], D.flen[fj], &first);
+        cand = (P.d == 1) || (nmut >= P.d - 1);
+    }
+    bool adj = cand;
+    unsigned long long todo = __ballot(cand && P.d > 1);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int cj = __shfl(fj, src, WAVE);
+        const int cn = __shfl(nmut, src, WAVE);
+        const int cv = __shfl(first, src, WAVE);
+        const int *cL = D.fpool + D.foff[cj];
+        const int cnj = D.flen[cj];
+        const int *pool = P.pool + P.inc_off[cv];
+        const int npool = P.inc_len[cv];
+        bool found = false;
+        for (int base = 0; base < npool; base += WAVE) {
+            int k = base + lane;
+            bool hit = false;
+            if (k < npool) {
+                int w = pool[k];
+                if (w != fi && w != cj && D.flive[w] && D.flen[w] >= cn)
+                    hit = isect3_count(A, ni, cL, cnj, D.fpool + D.foff[w], D.flen[w]) == cn;
+            }
+            if (__ballot(hit)) { found = true; break; }
+        }
+        if (lane == src) adj = !found;
+    }
+    Tri t{adj ? 1 : 0, 0, 0};
+    pflag[(size_t)blockIdx.x * PB + threadIdx.x] = adj ? 1 : 0;
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+}  // namespace bslv
+
+using namespace bslv;
+
+struct bslv_poly {
+    int d = 0, v2h = 0;
+    std::vector<double> c;
+    hipStream_t stream = nullptr;
+    PolyView P{};
+    int nv = 0;                       // primal slots in use
+    unsigned poolcap = 0, poolused = 0;
+    int2 *E[2] = {nullptr, nullptr};
+    int ecap = 0, ne = 0, ecur = 0;
+    unsigned char *eflag = nullptr;   // ecap
+    int *members = nullptr;           // cap
+    Tri *bsum = nullptr; int bsumcap = 0;
+    Tri *totals = nullptr;            // device, 4 entries
+    int *counters = nullptr;          // device, 4 ints
+    Tri *totals_h = nullptr; int *counters_h = nullptr;   // pinned
+    PairBlk *blks = nullptr; int blkcap = 0;
+    unsigned char *pflag = nullptr; size_t pflagcap = 0;
+    // dual side (host)
+    std::vector<double> Y, hp;        // nf x d, nf x (d+1)
+    std::vector<unsigned char> fapplied, fideal;
+    int nf = 0;
+    bool initialised = false;
+    std::vector<int> queue;
+    std::vector<int> dual_edges;      // pairs, filled by dual_adjacency
+    // stats
+    long pair_tests = 0, new_vertices = 0, cuts_applied = 0;
+    // scratch for batched classify
+    double *hps_d = nullptr; int hpscap = 0;
+    unsigned long long *clsw = nullptr; size_t clswcap = 0;
+    int *anyminus = nullptr; int anycap = 0;
+    int *idx_d = nullptr; double *val_d = nullptr; unsigned char *fl_d = nullptr; int outcap = 0;
+};
+
+static void v2h_map(const bslv_poly *h, const double *v, int is_dir, double *hp)
+{
+    const int d = h->d;
+    switch (h->v2h) {
+    case 0:   // cone_polar, bslv_poly.c:30-39
+        for (int j = 0; j < d; j++) hp[j] = v[j];
+        hp[d] = is_dir ? 0.0 : -1.0;
+        break;
+    case 1:   // lowerV2upperH, bslv_algs.c:287-305
+        if (is_dir) { for (int j = 0; j < d; j++) hp[j] = 0.0; hp[d] = -1.0; }
+        else {
+            hp[d - 1] = 1.0;
+            for (int j = 0; j < d - 1; j++) { hp[j] = v[j]; hp[d - 1] -= h->c[j] * hp[j]; }
+            hp[d] = v[d - 1];
+        }
+        break;
+    default:  // upperV2lowerH, bslv_algs.c:307-313
+        hp[d - 1] = is_dir ? 0.0 : -1.0;
+        for (int j = 0; j < d - 1; j++) hp[j] = v[j] - v[d - 1] * h->c[j];
+        hp[d] = -v[d - 1];
+        break;
+    }
+}
+
+template <typename T>
+static int grow(T **p, size_t oldn, size_t newn, hipStream_t s, bool zero_tail = false)
+{
+    T *q = nullptr;
+    HIP_TRY(hipMalloc(&q, newn * sizeof(T)));
+    if (*p && oldn) HIP_TRY(hipMemcpyAsync(q, *p, oldn * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (zero_tail) HIP_TRY(hipMemsetAsync(q + oldn, 0, (newn - oldn) * sizeof(T), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*p) (void)hipFree(*p);
+    *p = q;
+    return 0;
+}
+
+static int ensure_vcap(bslv_poly *h, int need)
+{
+    if (need <= h->P.cap) return 0;
+    int ncap = std::max(need, std::max(1024, h->P.cap * 2));
+    PolyView &P = h->P;
+    // SoA coordinates: re-stride
+    double *X = nullptr;
+    HIP_TRY(hipMalloc(&X, (size_t)h->d * ncap * sizeof(double)));
+    for (int k = 0; k < h->d && P.X && h->nv; k++)
+        HIP_TRY(hipMemcpyAsync(X + (size_t)k * ncap, P.X + (size_t)k * P.cap, (size_t)h->nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (P.X) (void)hipFree(P.X);
+    P.X = X;
+    int rc;
+    if ((rc = grow(&P.flag, h->nv, ncap, h->stream, true))) return rc;
+    if ((rc = grow(&P.cls, h->nv, ncap, h->stream))) return rc;   // classes of the cut in flight survive a re-allocation
+    if ((rc = grow(&P.inc_off, h->nv, ncap, h->stream))) return rc;
+    if ((rc = grow(&P.inc_len, h->nv, ncap, h->stream))) return rc;
+    if ((rc = grow(&h->members, 0, ncap, h->stream))) return rc;
+    P.cap = ncap;
+    return 0;
+}
+static int ensure_pool(bslv_poly *h, size_t need)
+{
+    if (need <= h->poolcap) return 0;
+    if (need > 0xF0000000ull) { set_error("incidence pool exceeds 32-bit offsets"); return BSLV_E_CAPACITY; }
+    size_t ncap = std::min<size_t>(0xF0000000ull, std::max(need, std::max<size_t>(1 << 16, (size_t)h->poolcap * 2)));
+    int rc;
+    if ((rc = grow(&h->P.pool, h->poolused, ncap, h->stream))) return rc;
+    if ((rc = grow(&h->P.keep, h->poolused, ncap, h->stream, true))) return rc;
+    h->poolcap = (unsigned)ncap;
+    return 0;
+}
+static int ensure_ecap(bslv_poly *h, int need)
+{
+    if (need <= h->ecap) return 0;
+    int ncap = std::max(need, std::max(4096, h->ecap * 2));
+    int rc;
+    if ((rc = grow(&h->E[h->ecur], h->ne, ncap, h->stream))) return rc;
+    if ((rc = grow(&h->E[1 - h->ecur], 0, ncap, h->stream))) return rc;
+    if ((rc = grow(&h->eflag, 0, ncap, h->stream))) return rc;
+    h->ecap = ncap;
+    return 0;
+}
+static int ensure_bsum(bslv_poly *h, int nb)
+{
+    if (nb <= h->bsumcap) return 0;
+    int ncap = std::max(nb, std::max(1024, h->bsumcap * 2));
+    int rc;
+    if ((rc = grow(&h->bsum, 0, ncap, h->stream))) return rc;
+    h->bsumcap = ncap;
+    return 0;
+}
+
+// run the three-kernel scan tail: bsum -> exclusive prefixes, totals -> host
+static int scan_totals(bslv_poly *h, int nb, Tri *tot_out)
+{
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, h->stream, h->bsum, nb, h->totals);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->totals_h, h->totals, sizeof(Tri), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *tot_out = h->totals_h[0];
+    return 0;
+}
+
+static int new_dual(bslv_poly *h, const double *val, int ideal)
+{
+    int f = h->nf++;
+    h->Y.insert(h->Y.end(), val, val + h->d);
+    h->hp.resize((size_t)h->nf * (h->d + 1));
+    v2h_map(h, val, ideal, &h->hp[(size_t)f * (h->d + 1)]);
+    h->fapplied.push_back(1);
+    h->fideal.push_back(ideal ? 1 : 0);
+    return f;
+}
+
+// one cut on the device; *rc = 0 cut applied, 1 redundant
+static int do_cut(bslv_poly *h, int f, int *rc_out)
+{
+    const int d = h->d, nv0 = h->nv;
+    hipStream_t s = h->stream;
+    Hp hp;
+    memset(&hp, 0, sizeof(hp));
+    memcpy(hp.h, &h->hp[(size_t)f * (d + 1)], (d + 1) * sizeof(double));
+    int rc;
+    // K1
+    HIP_TRY(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), s));
+    const int nbv = (nv0 + PB - 1) / PB;
+    hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, h->counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->counters_h, h->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int nminus = h->counters_h[0], nzero = h->counters_h[1];
+    if (nminus == 0) { h->fapplied[f] = 0; *rc_out = 1; return 0; }
+    // E: flags + scan
+    const int ne0 = h->ne, nbe = (ne0 + PB - 1) / PB;
+    if ((rc = ensure_bsum(h, std::max(nbe, nbv) + 1))) return rc;
+    const int2 *Eold = h->E[h->ecur];
+    int2 *Enew = h->E[1 - h->ecur];
+    Tri te{0, 0, 0};
+    if (ne0 > 0) {
+        hipLaunchKernelGGL(k_edge_flags, dim3(nbe), dim3(PB), 0, s, h->P, Eold, ne0, h->eflag, h->bsum);
+        if ((rc = scan_totals(h, nbe, &te))) return rc;
+    }
+    const int nsurv = te.a, ncross = te.b;
+    if ((rc = ensure_vcap(h, nv0 + ncross))) return rc;
+    if ((rc = ensure_pool(h, (size_t)h->poolused + te.c))) return rc;
+    const unsigned pool_e = h->poolused;
+    if (ne0 > 0) {
+        hipLaunchKernelGGL(k_edge_emit, dim3(nbe), dim3(PB), 0, s, h->P, hp, f, Eold, ne0, h->eflag, h->bsum, h->totals, Enew,
+                           nv0, pool_e);
+        HIP_TRY(hipGetLastError());
+    }
+    h->poolused += te.c;
+    // Z: on-plane elements (+ clears used on MINUS)
+    Tri tz{0, 0, 0};
+    hipLaunchKernelGGL(k_vert_flags, dim3(nbv), dim3(PB), 0, s, h->P, nv0, h->bsum);
+    if ((rc = scan_totals(h, nbv, &tz))) return rc;
+    if (tz.a != nzero) { set_error("internal: ZERO count mismatch %d vs %d", tz.a, nzero); return BSLV_E_STATE; }
+    if ((rc = ensure_pool(h, (size_t)h->poolused + tz.c))) return rc;
+    hipLaunchKernelGGL(k_vert_emit, dim3(nbv), dim3(PB), 0, s, h->P, f, nv0, h->bsum, h->members, h->poolused);
+    h->poolused += tz.c;
+    if (ncross > 0) hipLaunchKernelGGL(k_iota_members, dim3((ncross + 255) / 256), dim3(256), 0, s, h->members, nzero, nv0, ncross);
+    HIP_TRY(hipGetLastError());
+    h->nv = nv0 + ncross;
+    h->ne = nsurv + ncross;
+    h->ecur = 1 - h->ecur;
+    h->new_vertices += ncross;
+    // K2: pairs of members
+    const int nm = nzero + ncross;
+    if (nm >= 2) {
+        std::vector<PairBlk> blks;
+        for (int i = 0; i + 1 < nm; i++)
+            for (int j0 = i + 1; j0 < nm; j0 += PB) blks.push_back(PairBlk{i, j0});
+        const int nbp = (int)blks.size();
+        h->pair_tests += (long)nm * (nm - 1) / 2;
+        if (nbp > h->blkcap) { if ((rc = grow(&h->blks, 0, (size_t)std::max(nbp, h->blkcap * 2), s))) return rc; h->blkcap = std::max(nbp, h->blkcap * 2); }
+        if ((size_t)nbp * PB > h->pflagcap) { size_t nc = std::max((size_t)nbp * PB, h->pflagcap * 2); if ((rc = grow(&h->pflag, 0, nc, s))) return rc; h->pflagcap = nc; }
+        if ((rc = ensure_bsum(h, nbp + 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->blks, blks.data(), (size_t)nbp * sizeof(PairBlk), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pair_flags, dim3(nbp), dim3(PB), 0, s, h->P, h->members, nm, h->blks, h->pflag, h->bsum);
+        Tri tp{0, 0, 0};
+        if ((rc = scan_totals(h, nbp, &tp))) return rc;
+        if (tp.a > 0) {
+            if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
+            hipLaunchKernelGGL(k_pair_emit, dim3(nbp), dim3(PB), 0, s, h->members, h->blks, h->pflag, h->bsum, h->E[h->ecur], h->ne);
+            HIP_TRY(hipGetLastError());
+            h->ne += tp.a;
+        }
+    }
+    // head-room for the next cut: every edge may cross
+    if ((rc = ensure_ecap(h, h->ne + 1))) return rc;
+    h->cuts_applied++;
+    *rc_out = 0;
+    return 0;
+}
+
+static int upload_initial(bslv_poly *h, const std::vector<double> &X /* (d+1) x d */, const std::vector<std::vector<int>> &inc)
+{
+    const int d = h->d, n = d + 1;
+    int rc;
+    if ((rc = ensure_vcap(h, 1024))) return rc;
+    size_t tot = 0;
+    for (auto &l : inc) tot += l.size();
+    if ((rc = ensure_pool(h, tot))) return rc;
+    if ((rc = ensure_ecap(h, 4096))) return rc;
+    std::vector<double> soa((size_t)d * n);
+    for (int i = 0; i < n; i++) for (int k = 0; k < d; k++) soa[(size_t)k * n + i] = X[(size_t)i * d + k];
+    for (int k = 0; k < d; k++)
+        HIP_TRY(hipMemcpy(h->P.X + (size_t)k * h->P.cap, &soa[(size_t)k * n], n * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<unsigned char> fl(n, F_USED);
+    for (int i = 1; i < n; i++) fl[i] |= F_IDEAL;
+    HIP_TRY(hipMemcpy(h->P.flag, fl.data(), n, hipMemcpyHostToDevice));
+    std::vector<unsigned> off(n);
+    std::vector<int> len(n), pool;
+    for (int i = 0; i < n; i++) { off[i] = (unsigned)pool.size(); len[i] = (int)inc[i].size(); pool.insert(pool.end(), inc[i].begin(), inc[i].end()); }
+    HIP_TRY(hipMemcpy(h->P.inc_off, off.data(), n * sizeof(unsigned), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->P.inc_len, len.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->P.pool, pool.data(), pool.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->poolused = (unsigned)pool.size();
+    std::vector<int2> E;
+    for (int k = 0; k <= d; k++) for (int j = k + 1; j <= d; j++) E.push_back(int2{k, j});
+    HIP_TRY(hipMemcpy(h->E[h->ecur], E.data(), E.size() * sizeof(int2), hipMemcpyHostToDevice));
+    h->ne = (int)E.size();
+    h->nv = n;
+    return 0;
+}
+
+// modified Gram-Schmidt step (bslv__normalise, bslv_poly.c:1030-1060)
+static double gs_step(const double *x, double *H, double *R, int k, int n)
+{
+    double nrm_in = 0, scl = 0;
+    for (int l = 0; l < n; l++) nrm_in += x[l] * x[l];
+    nrm_in = std::sqrt(nrm_in);
+    double *hr = H + (size_t)k * n;
+    for (int l = 0; l < n; l++) hr[l] = x[l];
+    for (int j = 0; j < k; j++) {
+        double s = 0;
+        for (int l = 0; l < n; l++) s += H[(size_t)j * n + l] * hr[l];
+        for (int l = 0; l < n; l++) hr[l] -= s * H[(size_t)j * n + l];
+    }
+    for (int l = 0; l < n; l++) scl += hr[l] * hr[l];
+    scl = std::sqrt(scl);
+    if (scl < 1.0e-6) return 0;
+    for (int l = 0; l < n; l++) hr[l] /= scl;
+    for (int j = 0; j <= k; j++) {
+        double s = 0;
+        for (int l = 0; l < n; l++) s += H[(size_t)j * n + l] * x[l];
+        R[k * (k + 1) / 2 + j] = s;
+    }
+    return scl / nrm_in;
+}
+
+extern "C" {
+
+int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
+{
+    if (!out || dim < 2 || dim > MAXD || v2h < 0 || v2h > 2) { set_error("bslv_poly_create: bad argument (2 <= dim <= %d)", MAXD); return BSLV_E_ARG; }
+    if (bslv_device_count() < 1) { set_error("no HIP device available"); return BSLV_E_NODEVICE; }
+    bslv_poly *h = new bslv_poly();
+    h->d = dim; h->v2h = v2h;
+    h->c.assign(dim, 0.0);
+    if (c) h->c.assign(c, c + dim);
+    h->P.d = dim;
+    auto fail = [&](int code) { bslv_poly_destroy(h); return code; };
+    if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
+    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, 4 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess) {
+        set_error("allocation of scan scratch failed");
+        return fail(BSLV_E_NOMEM);
+    }
+    // dual slot 0: "facet at infinity", ideal point (0,..,0,-1)  (bslv_poly.c:83-92)
+    std::vector<double> z(dim, 0.0);
+    z[dim - 1] = -1.0;
+    new_dual(h, z.data(), 1);
+    *out = h;
+    return 0;
+}
+
+void bslv_poly_destroy(bslv_poly *h)
+{
+    if (!h) return;
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters);
+    fr(h->blks); fr(h->pflag); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d);
+    if (h->totals_h) (void)hipHostFree(h->totals_h);
+    if (h->counters_h) (void)hipHostFree(h->counters_h);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int bslv_poly_dual0_apex(bslv_poly *h)
+{
+    if (!h) return BSLV_E_ARG;
+    h->fideal[0] = 0;
+    h->Y[h->d - 1] = 0.0;
+    v2h_map(h, h->Y.data(), 0, h->hp.data());
+    return 0;
+}
+
+int bslv_poly_add(bslv_poly *h, const double *val, int ideal, int *rc_out)
+{
+    if (!h || !val || !rc_out) { set_error("bslv_poly_add: bad argument"); return BSLV_E_ARG; }
+    int f = new_dual(h, val, ideal);
+    if (!h->initialised) { h->queue.push_back(f); *rc_out = 0; return 0; }
+    return do_cut(h, f, rc_out);
+}
+
+int bslv_poly_init(bslv_poly *h, int *rc_out)
+{
+    if (!h || !rc_out) return BSLV_E_ARG;
+    if (h->initialised) { set_error("bslv_poly_init: already initialised"); return BSLV_E_STATE; }
+    const int d = h->d;
+    int qn = (int)h->queue.size();
+    if (qn < d) { *rc_out = 1; return 0; }
+    std::vector<double> hpq((size_t)qn * (d + 1));
+    for (int k = 0; k < qn; k++) memcpy(&hpq[(size_t)k * (d + 1)], &h->hp[(size_t)h->queue[k] * (d + 1)], (d + 1) * sizeof(double));
+    std::vector<double> H((size_t)d * d, 0.0), R((size_t)d * (d + 1) / 2, 0.0), alph(d, 0.0);
+    std::vector<int> perm(d + 1, 0);
+    int g = 0;
+    // greedy choice of d independent halfspaces (poly__intl_apprx, bslv_poly.c:167-185)
+    while (g < d) {
+        double best = 0; int bi = -1;
+        for (int k = 0; k < qn; k++) {
+            double s = gs_step(&hpq[(size_t)k * (d + 1)], H.data(), R.data(), g, d);
+            if (best < s) { best = s; bi = k; }
+        }
+        if (best < 1.0e-10) { *rc_out = 1; return 0; }
+        gs_step(&hpq[(size_t)bi * (d + 1)], H.data(), R.data(), g, d);
+        alph[g] = hpq[(size_t)bi * (d + 1) + d];
+        perm[++g] = h->queue[bi];
+        qn--;
+        memcpy(&hpq[(size_t)bi * (d + 1)], &hpq[(size_t)qn * (d + 1)], (d + 1) * sizeof(double));
+        h->queue[bi] = h->queue[qn];
+    }
+    // initial simplex cone (poly__poly_initialise, bslv_poly.c:711-787)
+    auto RM = [&](int k, int j) -> double & { return R[k * (k + 1) / 2 + j]; };
+    std::vector<double> X((size_t)(d + 1) * d, 0.0), t(d, 0.0);
+    for (int k = 0; k < d; k++) {
+        double s = alph[k];
+        for (int j = 0; j < k; j++) s -= RM(k, j) * t[j];
+        t[k] = s / RM(k, k);
+    }
+    for (int j = 0; j < d; j++) { double s = 0; for (int l = 0; l < d; l++) s += H[(size_t)l * d + j] * t[l]; X[j] = s; }
+    for (int k = 0; k < d; k++) {
+        std::fill(t.begin(), t.end(), 0.0);
+        t[k] = 1.0 / RM(k, k);
+        for (int i = k + 1; i < d; i++) {
+            double s = 0;
+            for (int j = k; j < i; j++) s += RM(i, j) * t[j];
+            t[i] = -s / RM(i, i);
+        }
+        for (int j = 0; j < d; j++) { double s = 0; for (int l = 0; l < d; l++) s += H[(size_t)l * d + j] * t[l]; X[(size_t)(k + 1) * d + j] = s; }
+    }
+    std::vector<std::vector<int>> inc(d + 1);
+    for (int j = 0; j <= d; j++) {
+        for (int k = 0; k <= d; k++) if (k != j) inc[j].push_back(perm[k]);
+        std::sort(inc[j].begin(), inc[j].end());
+    }
+    int rc;
+    if ((rc = upload_initial(h, X, inc))) return rc;
+    h->initialised = true;
+    // halfspaces not chosen are re-added as NEW dual slots; originals stay unused (bslv_poly.c:190-197)
+    std::vector<int> rest(h->queue.begin(), h->queue.begin() + qn);
+    h->queue.clear();
+    for (int f : rest) h->fapplied[f] = 0;
+    for (int f : rest) {
+        std::vector<double> val(h->Y.begin() + (size_t)f * d, h->Y.begin() + (size_t)(f + 1) * d);
+        int r2;
+        if ((rc = bslv_poly_add(h, val.data(), h->fideal[f], &r2))) return rc;
+    }
+    *rc_out = 0;
+    return 0;
+}
+
+// Batched poly__add_vrtx: B dual vertices in order.  A batched incidence pass (k_classify_batch)
+// first finds the halfspaces no live element violates -- by convexity they stay redundant
+// whatever the earlier cuts of the batch do -- and only the others run the per-cut pipeline.
+int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal, int *rc_out)
+{
+    if (!h || B < 0 || (B > 0 && (!val || !rc_out))) { set_error("bslv_poly_add_cuts: bad argument"); return BSLV_E_ARG; }
+    if (!h->initialised) {
+        for (int b = 0; b < B; b++) { int r; int rc = bslv_poly_add(h, val + (size_t)b * h->d, ideal ? ideal[b] : 0, &r); if (rc) return rc; rc_out[b] = r; }
+        return 0;
+    }
+    const int d = h->d;
+    std::vector<int> fids(B);
+    for (int b = 0; b < B; b++) fids[b] = new_dual(h, val + (size_t)b * d, ideal ? ideal[b] : 0);
+    std::vector<int> anym(B, 1);
+    if (B >= 2) {
+        int rc;
+        const int nv = h->nv;
+        const int chunkB = 512;        // halfspaces per launch: (d+1)*8*512 B of LDS
+        for (int b0 = 0; b0 < B; b0 += chunkB) {
+            int nb_ = std::min(chunkB, B - b0);
+            if (nb_ > h->hpscap) { if ((rc = grow(&h->hps_d, 0, (size_t)chunkB * (MAXD + 1), h->stream))) return rc; h->hpscap = chunkB; }
+            if (nb_ > h->anycap) { if ((rc = grow(&h->anyminus, 0, (size_t)chunkB, h->stream))) return rc; h->anycap = chunkB; }
+            size_t need = (size_t)((nb_ + 31) / 32) * h->P.cap;
+            if (need > h->clswcap) { if ((rc = grow(&h->clsw, 0, need, h->stream))) return rc; h->clswcap = need; }
+            HIP_TRY(hipMemcpyAsync(h->hps_d, &h->hp[(size_t)fids[b0] * (d + 1)], (size_t)nb_ * (d + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemsetAsync(h->anyminus, 0, nb_ * sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_classify_batch, dim3((nv + PB - 1) / PB), dim3(PB), (size_t)nb_ * (d + 1) * sizeof(double), h->stream,
+                               h->P, h->hps_d, nb_, nv, h->clsw, h->anyminus);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&anym[b0], h->anyminus, nb_ * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    for (int b = 0; b < B; b++) {
+        if (!anym[b]) { h->fapplied[fids[b]] = 0; rc_out[b] = 1; continue; }
+        int r, rc = do_cut(h, fids[b], &r);
+        if (rc) return rc;
+        rc_out[b] = r;
+    }
+    return 0;
+}
+
+// Stand-alone batched incidence kernel for tests and the roofline measurement: classes of the
+// current elements against B arbitrary halfspaces (hps: B x (dim+1), normal then alpha).
+// words_out (host, may be NULL): ceil(B/32) x nv 64-bit words; anyminus_out (host, may be NULL): B ints.
+int bslv_poly_classify_batch(bslv_poly *h, int B, const double *hps, unsigned long long *words_out, int *anyminus_out, int repeats, float *ms_out)
+{
+    if (!h || B < 1 || !hps || !h->initialised) { set_error("bslv_poly_classify_batch: bad argument"); return BSLV_E_ARG; }
+    const int d = h->d, nv = h->nv;
+    if ((size_t)B * (d + 1) * sizeof(double) > 60 * 1024) { set_error("classify_batch: B too large for LDS"); return BSLV_E_ARG; }
+    int rc;
+    if (B > h->hpscap) { if ((rc = grow(&h->hps_d, 0, (size_t)B * (MAXD + 1), h->stream))) return rc; h->hpscap = B; }
+    if (B > h->anycap) { if ((rc = grow(&h->anyminus, 0, (size_t)B, h->stream))) return rc; h->anycap = B; }
+    size_t need = (size_t)((B + 31) / 32) * h->P.cap;
+    if (need > h->clswcap) { if ((rc = grow(&h->clsw, 0, need, h->stream))) return rc; h->clswcap = need; }
+    HIP_TRY(hipMemcpyAsync(h->hps_d, hps, (size_t)B * (d + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->anyminus, 0, B * sizeof(int), h->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    if (repeats < 1) repeats = 1;
+    // one untimed launch, then `repeats` timed ones
+    for (int it = 0; it <= repeats; it++) {
+        if (it == 1) HIP_TRY(hipEventRecord(e0, h->stream));
+        hipLaunchKernelGGL(k_classify_batch, dim3((nv + PB - 1) / PB), dim3(PB), (size_t)B * (d + 1) * sizeof(double), h->stream,
+                           h->P, h->hps_d, B, nv, h->clsw, h->anyminus);
+    }
+    HIP_TRY(hipEventRecord(e1, h->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / repeats;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (words_out)
+        for (int w = 0; w < (B + 31) / 32; w++)
+            HIP_TRY(hipMemcpy(words_out + (size_t)w * nv, h->clsw + (size_t)w * h->P.cap, (size_t)nv * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (anyminus_out) HIP_TRY(hipMemcpy(anyminus_out, h->anyminus, B * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// all unprocessed elements (used && !sltn) in ascending slot order: the set poly__get_vrtx
+// iterates (bslv_poly.c:214-216).  *count = how many exist; at most max_out are written.
+int bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count)
+{
+    if (!h || !count || max_out < 0) { set_error("bslv_poly_unprocessed: bad argument"); return BSLV_E_ARG; }
+    *count = 0;
+    if (!h->initialised || h->nv == 0) return 0;
+    int rc;
+    const int nv = h->nv, nb = (nv + PB - 1) / PB;
+    if ((rc = ensure_bsum(h, nb + 1))) return rc;
+    hipLaunchKernelGGL(k_unproc_flags, dim3(nb), dim3(PB), 0, h->stream, h->P, nv, h->bsum);
+    Tri t;
+    if ((rc = scan_totals(h, nb, &t))) return rc;
+    *count = t.a;
+    int n = std::min(t.a, max_out);
+    if (n == 0 || !idx) return 0;
+    if (n > h->outcap) {
+        int nc = std::max(n, h->outcap * 2);
+        if ((rc = grow(&h->idx_d, 0, (size_t)nc, h->stream))) return rc;
+        if ((rc = grow(&h->val_d, 0, (size_t)nc * h->d, h->stream))) return rc;
+        if ((rc = grow(&h->fl_d, 0, (size_t)nc, h->stream))) return rc;
+        h->outcap = nc;
+    }
+    hipLaunchKernelGGL(k_unproc_emit, dim3(nb), dim3(PB), 0, h->stream, h->P, nv, h->bsum, n, h->idx_d, h->val_d, h->fl_d);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned char> fl(n);
+    HIP_TRY(hipMemcpyAsync(idx, h->idx_d, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (val) HIP_TRY(hipMemcpyAsync(val, h->val_d, (size_t)n * h->d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(fl.data(), h->fl_d, n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (ideal) for (int k = 0; k < n; k++) ideal[k] = (fl[k] & F_IDEAL) ? 1 : 0;
+    return 0;
+}
+
+// poly__get_vrtx (bslv_poly.c:210-226): *rc = 1 when nothing is left
+int bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out)
+{
+    if (!h || !val || !ideal || !idx || !rc_out) return BSLV_E_ARG;
+    int cnt = 0;
+    int rc = bslv_poly_unprocessed(h, 1, idx, val, ideal, &cnt);
+    if (rc) return rc;
+    *rc_out = cnt > 0 ? 0 : 1;
+    return 0;
+}
+
+// ST_BT(primal.sltn, idx) for a list of slots
+int bslv_poly_mark(bslv_poly *h, int n, const int *idx)
+{
+    if (!h || n < 0 || (n > 0 && !idx)) return BSLV_E_ARG;
+    if (n == 0) return 0;
+    for (int k = 0; k < n; k++) if (idx[k] < 0 || idx[k] >= h->nv) { set_error("bslv_poly_mark: slot %d out of range", idx[k]); return BSLV_E_ARG; }
+    int rc;
+    if (n > h->outcap) {
+        int nc = std::max(n, h->outcap * 2);
+        if ((rc = grow(&h->idx_d, 0, (size_t)nc, h->stream))) return rc;
+        if ((rc = grow(&h->val_d, 0, (size_t)nc * h->d, h->stream))) return rc;
+        if ((rc = grow(&h->fl_d, 0, (size_t)nc, h->stream))) return rc;
+        h->outcap = nc;
+    }
+    HIP_TRY(hipMemcpyAsync(h->idx_d, idx, n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->P, h->idx_d, n, F_SLTN);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int bslv_poly_dim(const bslv_poly *h) { return h ? h->d : 0; }
+int bslv_poly_nprimal(const bslv_poly *h) { return h ? h->nv : 0; }
+int bslv_poly_ndual(const bslv_poly *h) { return h ? h->nf : 0; }
+long bslv_poly_nedges(const bslv_poly *h) { return h ? h->ne : 0; }
+long bslv_poly_pair_tests(const bslv_poly *h) { return h ? h->pair_tests : 0; }
+long bslv_poly_new_vertices(const bslv_poly *h) { return h ? h->new_vertices : 0; }
+
+// slot-indexed dumps (host buffers sized by the counts above)
+int bslv_poly_get_primal(bslv_poly *h, unsigned char *used, unsigned char *ideal, unsigned char *sltn, double *coords)
+{
+    if (!h) return BSLV_E_ARG;
+    const int nv = h->nv, d = h->d;
+    if (nv == 0) return 0;
+    std::vector<unsigned char> fl(nv);
+    HIP_TRY(hipMemcpy(fl.data(), h->P.flag, nv, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nv; i++) {
+        if (used) used[i] = (fl[i] & F_USED) ? 1 : 0;
+        if (ideal) ideal[i] = (fl[i] & F_IDEAL) ? 1 : 0;
+        if (sltn) sltn[i] = (fl[i] & F_SLTN) ? 1 : 0;
+    }
+    if (coords) {
+        std::vector<double> col(nv);
+        for (int k = 0; k < d; k++) {
+            HIP_TRY(hipMemcpy(col.data(), h->P.X + (size_t)k * h->P.cap, (size_t)nv * sizeof(double), hipMemcpyDeviceToHost));
+            for (int i = 0; i < nv; i++) coords[(size_t)i * d + k] = col[i];
+        }
+    }
+    return 0;
+}
+
+static int fetch_inc(bslv_poly *h, std::vector<unsigned char> &fl, std::vector<unsigned> &off, std::vector<int> &len, std::vector<int> &pool)
+{
+    const int nv = h->nv;
+    fl.resize(nv); off.resize(nv); len.resize(nv); pool.resize(h->poolused);
+    if (nv == 0) return 0;
+    HIP_TRY(hipMemcpy(fl.data(), h->P.flag, nv, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(off.data(), h->P.inc_off, nv * sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(len.data(), h->P.inc_len, nv * sizeof(int), hipMemcpyDeviceToHost));
+    if (h->poolused) HIP_TRY(hipMemcpy(pool.data(), h->P.pool, (size_t)h->poolused * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+long bslv_poly_ninc(bslv_poly *h)
+{
+    if (!h || h->nv == 0) return 0;
+    std::vector<unsigned char> fl(h->nv);
+    std::vector<int> len(h->nv);
+    if (hipMemcpy(fl.data(), h->P.flag, h->nv, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(len.data(), h->P.inc_len, h->nv * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    long n = 0;
+    for (int i = 0; i < h->nv; i++) if (fl[i] & F_USED) n += len[i];
+    return n;
+}
+
+int bslv_poly_get_inc(bslv_poly *h, int *pairs)
+{
+    if (!h || !pairs) return BSLV_E_ARG;
+    std::vector<unsigned char> fl; std::vector<unsigned> off; std::vector<int> len, pool;
+    int rc = fetch_inc(h, fl, off, len, pool);
+    if (rc) return rc;
+    long n = 0;
+    for (int i = 0; i < h->nv; i++) {
+        if (!(fl[i] & F_USED)) continue;
+        for (int j = 0; j < len[i]; j++) { pairs[2 * n] = i; pairs[2 * n + 1] = pool[off[i] + j]; n++; }
+    }
+    return 0;
+}
+
+int bslv_poly_get_edges(bslv_poly *h, int *ab)
+{
+    if (!h || !ab) return BSLV_E_ARG;
+    if (h->ne) HIP_TRY(hipMemcpy(ab, h->E[h->ecur], (size_t)h->ne * sizeof(int2), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// a dual slot is live iff it was applied and some live element lies on it
+int bslv_poly_get_dual(bslv_poly *h, unsigned char *used, unsigned char *ideal, double *coords)
+{
+    if (!h) return BSLV_E_ARG;
+    const int nf = h->nf;
+    std::vector<unsigned char> live(nf, 0);
+    if (h->initialised) {
+        std::vector<unsigned char> fl; std::vector<unsigned> off; std::vector<int> len, pool;
+        int rc = fetch_inc(h, fl, off, len, pool);
+        if (rc) return rc;
+        for (int i = 0; i < h->nv; i++) {
+            if (!(fl[i] & F_USED)) continue;
+            for (int j = 0; j < len[i]; j++) { int f = pool[off[i] + j]; if (h->fapplied[f]) live[f] = 1; }
+        }
+    } else
+        for (int f = 0; f < nf; f++) live[f] = h->fapplied[f];
+    if (used) memcpy(used, live.data(), nf);
+    if (ideal) memcpy(ideal, h->fideal.data(), nf);
+    if (coords) memcpy(coords, h->Y.data(), (size_t)nf * h->d * sizeof(double));
+    return 0;
+}
+
+// poly__update_adjacence on the dual side (bslv_poly.c:992-1010, called bslv_algs.c:398,1144,1569):
+// all pairs of live facets through the same pair kernel, on the transposed incidence.
+int bslv_poly_dual_adjacency(bslv_poly *h)
+{
+    if (!h) return BSLV_E_ARG;
+    h->dual_edges.clear();
+    if (!h->initialised) return 0;
+    std::vector<unsigned char> fl; std::vector<unsigned> off; std::vector<int> len, pool;
+    int rc = fetch_inc(h, fl, off, len, pool);
+    if (rc) return rc;
+    const int nf = h->nf;
+    std::vector<int> flen(nf, 0);
+    std::vector<unsigned char> live(nf, 0);
+    for (int i = 0; i < h->nv; i++) if (fl[i] & F_USED) for (int j = 0; j < len[i]; j++) { int f = pool[off[i] + j]; flen[f]++; if (h->fapplied[f]) live[f] = 1; }
+    std::vector<unsigned> foff(nf + 1, 0);
+    for (int f = 0; f < nf; f++) foff[f + 1] = foff[f] + flen[f];
+    std::vector<int> fpool(foff[nf] ? foff[nf] : 1), fill(nf, 0), ids;
+    for (int i = 0; i < h->nv; i++) if (fl[i] & F_USED) for (int j = 0; j < len[i]; j++) { int f = pool[off[i] + j]; fpool[foff[f] + fill[f]++] = i; }
+    for (int f = 0; f < nf; f++) if (live[f]) ids.push_back(f);
+    const int nm = (int)ids.size();
+    if (nm < 2) return 0;
+    hipStream_t s = h->stream;
+    int *ids_d = nullptr, *flen_d = nullptr, *fpool_d = nullptr; unsigned *foff_d = nullptr; unsigned char *live_d = nullptr;
+    int2 *out_d = nullptr;
+    auto cleanup = [&]() { for (void *p : {(void *)ids_d, (void *)flen_d, (void *)fpool_d, (void *)foff_d, (void *)live_d, (void *)out_d}) if (p) (void)hipFree(p); };
+#define TRYC(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(_e)); cleanup(); return BSLV_E_NODEVICE; } } while (0)
+    TRYC(hipMalloc(&ids_d, nm * sizeof(int)));
+    TRYC(hipMalloc(&flen_d, nf * sizeof(int)));
+    TRYC(hipMalloc(&foff_d, (nf + 1) * sizeof(unsigned)));
+    TRYC(hipMalloc(&fpool_d, fpool.size() * sizeof(int)));
+    TRYC(hipMalloc(&live_d, nf));
+    TRYC(hipMemcpy(ids_d, ids.data(), nm * sizeof(int), hipMemcpyHostToDevice));
+    TRYC(hipMemcpy(flen_d, flen.data(), nf * sizeof(int), hipMemcpyHostToDevice));
+    TRYC(hipMemcpy(foff_d, foff.data(), (nf + 1) * sizeof(unsigned), hipMemcpyHostToDevice));
+    TRYC(hipMemcpy(fpool_d, fpool.data(), fpool.size() * sizeof(int), hipMemcpyHostToDevice));
+    TRYC(hipMemcpy(live_d, live.data(), nf, hipMemcpyHostToDevice));
+    DualView D{ids_d, foff_d, flen_d, fpool_d, live_d};
+    // rows are processed in slabs so the block table and flag array stay bounded
+    const long max_blocks = 1 << 20;
+    int row = 0;
+    while (row + 1 < nm) {
+        std::vector<PairBlk> blks;
+        int r1 = row;
+        while (r1 + 1 < nm && (long)blks.size() + (nm - r1 - 1 + PB - 1) / PB <= max_blocks) {
+            for (int j0 = r1 + 1; j0 < nm; j0 += PB) blks.push_back(PairBlk{r1, j0});
+            r1++;
+        }
+        if (r1 == row) { set_error("dual adjacency: a single row exceeds the block budget"); cleanup(); return BSLV_E_CAPACITY; }
+        const int nbp = (int)blks.size();
+        for (int i = row; i < r1; i++) h->pair_tests += nm - 1 - i;
+        if (nbp > h->blkcap) { if ((rc = grow(&h->blks, 0, (size_t)nbp, s))) { cleanup(); return rc; } h->blkcap = nbp; }
+        if ((size_t)nbp * PB > h->pflagcap) { if ((rc = grow(&h->pflag, 0, (size_t)nbp * PB, s))) { cleanup(); return rc; } h->pflagcap = (size_t)nbp * PB; }
+        if ((rc = ensure_bsum(h, nbp + 1))) { cleanup(); return rc; }
+        TRYC(hipMemcpyAsync(h->blks, blks.data(), (size_t)nbp * sizeof(PairBlk), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_dpair_flags, dim3(nbp), dim3(PB), 0, s, h->P, D, nm, h->blks, h->pflag, h->bsum);
+        Tri tp{0, 0, 0};
+        if ((rc = scan_totals(h, nbp, &tp))) { cleanup(); return rc; }
+        if (tp.a > 0) {
+            if (out_d) { (void)hipFree(out_d); out_d = nullptr; }
+            TRYC(hipMalloc(&out_d, (size_t)tp.a * sizeof(int2)));
+            hipLaunchKernelGGL(k_pair_emit, dim3(nbp), dim3(PB), 0, s, ids_d, h->blks, h->pflag, h->bsum, out_d, 0);
+            size_t base = h->dual_edges.size();
+            h->dual_edges.resize(base + 2 * (size_t)tp.a);
+            TRYC(hipMemcpyAsync(&h->dual_edges[base], out_d, (size_t)tp.a * sizeof(int2), hipMemcpyDeviceToHost, s));
+            TRYC(hipStreamSynchronize(s));
+        }
+        row = r1;
+    }
+#undef TRYC
+    cleanup();
+    return 0;
+}
+
+long bslv_poly_ndual_edges(const bslv_poly *h) { return h ? (long)h->dual_edges.size() / 2 : 0; }
+int bslv_poly_get_dual_edges(bslv_poly *h, int *ab)
+{
+    if (!h || !ab) return BSLV_E_ARG;
+    memcpy(ab, h->dual_edges.data(), h->dual_edges.size() * sizeof(int));
+    return 0;
+}
+
+}  // extern "C"

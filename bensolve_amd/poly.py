@@ -1,0 +1,142 @@
+"""Host-side mirror of the reference's polyhedron interface (bslv_poly.h:90-118) over the HIP engine."""
+import ctypes
+import numpy as np
+from ._lib import load_library, check
+
+CONE_POLAR, LOWER2UPPER, UPPER2LOWER = 0, 1, 2
+_bound = False
+
+
+def _bind(lib):
+    global _bound
+    if _bound:
+        return
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    lib.bslv_poly_create.argtypes = [ctypes.POINTER(vp), i, i, vp]
+    lib.bslv_poly_destroy.argtypes = [vp]
+    lib.bslv_poly_destroy.restype = None
+    lib.bslv_poly_dual0_apex.argtypes = [vp]
+    lib.bslv_poly_add.argtypes = [vp, vp, i, vp]
+    lib.bslv_poly_add_cuts.argtypes = [vp, i, vp, vp, vp]
+    lib.bslv_poly_init.argtypes = [vp, vp]
+    lib.bslv_poly_next.argtypes = [vp, vp, vp, vp, vp]
+    lib.bslv_poly_unprocessed.argtypes = [vp, i, vp, vp, vp, vp]
+    lib.bslv_poly_mark.argtypes = [vp, i, vp]
+    lib.bslv_poly_dual_adjacency.argtypes = [vp]
+    lib.bslv_poly_classify_batch.argtypes = [vp, i, vp, vp, vp, i, vp]
+    for n in ("dim", "nprimal", "ndual"):
+        getattr(lib, "bslv_poly_" + n).argtypes = [vp]
+    for n in ("nedges", "ninc", "ndual_edges", "pair_tests", "new_vertices"):
+        f = getattr(lib, "bslv_poly_" + n)
+        f.argtypes = [vp]
+        f.restype = ctypes.c_long
+    lib.bslv_poly_get_primal.argtypes = [vp, vp, vp, vp, vp]
+    lib.bslv_poly_get_dual.argtypes = [vp, vp, vp, vp]
+    lib.bslv_poly_get_edges.argtypes = [vp, vp]
+    lib.bslv_poly_get_inc.argtypes = [vp, vp]
+    lib.bslv_poly_get_dual_edges.argtypes = [vp, vp]
+    _bound = True
+
+
+class PolyEngine:
+    """poly_args-like object: primal polyhedron + dual, living in HBM."""
+
+    def __init__(self, dim, v2h=CONE_POLAR, c=None):
+        self.lib = load_library()
+        _bind(self.lib)
+        self.d = dim
+        cc = None if c is None else np.ascontiguousarray(c, np.float64)
+        h = ctypes.c_void_p()
+        check(self.lib.bslv_poly_create(ctypes.byref(h), dim, v2h, None if cc is None else cc.ctypes.data))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bslv_poly_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dual0_apex(self):
+        check(self.lib.bslv_poly_dual0_apex(self.h))
+
+    def add(self, val, ideal=0):
+        """poly__add_vrtx: 0 = added/queued, 1 = redundant"""
+        v = np.ascontiguousarray(val, np.float64)
+        rc = ctypes.c_int()
+        check(self.lib.bslv_poly_add(self.h, v.ctypes.data, int(ideal), ctypes.byref(rc)))
+        return rc.value
+
+    def add_cuts(self, vals, ideals=None):
+        vals = np.ascontiguousarray(vals, np.float64).reshape(-1, self.d)
+        B = len(vals)
+        rc = np.zeros(B, np.int32)
+        idl = None if ideals is None else np.ascontiguousarray(ideals, np.int32)
+        check(self.lib.bslv_poly_add_cuts(self.h, B, vals.ctypes.data, None if idl is None else idl.ctypes.data, rc.ctypes.data))
+        return rc
+
+    def init(self):
+        rc = ctypes.c_int()
+        check(self.lib.bslv_poly_init(self.h, ctypes.byref(rc)))
+        return rc.value
+
+    def next(self):
+        v = np.empty(self.d)
+        ideal, idx, rc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(self.lib.bslv_poly_next(self.h, v.ctypes.data, ctypes.byref(ideal), ctypes.byref(idx), ctypes.byref(rc)))
+        return None if rc.value else (v, ideal.value, idx.value)
+
+    def unprocessed(self, max_out=None):
+        cnt = ctypes.c_int()
+        check(self.lib.bslv_poly_unprocessed(self.h, 0, None, None, None, ctypes.byref(cnt)))
+        n = cnt.value if max_out is None else min(cnt.value, max_out)
+        idx = np.empty(n, np.int32)
+        val = np.empty((n, self.d))
+        ideal = np.empty(n, np.int32)
+        if n:
+            check(self.lib.bslv_poly_unprocessed(self.h, n, idx.ctypes.data, val.ctypes.data, ideal.ctypes.data, ctypes.byref(cnt)))
+        return idx, val, ideal, cnt.value
+
+    def mark(self, idx):
+        idx = np.ascontiguousarray(np.atleast_1d(idx), np.int32)
+        check(self.lib.bslv_poly_mark(self.h, len(idx), idx.ctypes.data))
+
+    def dual_adjacency(self):
+        check(self.lib.bslv_poly_dual_adjacency(self.h))
+
+    def classify_batch(self, hps, repeats=1, fetch=True):
+        hps = np.ascontiguousarray(hps, np.float64).reshape(-1, self.d + 1)
+        B = len(hps)
+        nv = self.lib.bslv_poly_nprimal(self.h)
+        words = np.zeros(((B + 31) // 32, nv), np.uint64) if fetch else None
+        anym = np.zeros(B, np.int32)
+        ms = ctypes.c_float()
+        check(self.lib.bslv_poly_classify_batch(self.h, B, hps.ctypes.data, None if words is None else words.ctypes.data,
+                                                anym.ctypes.data, repeats, ctypes.byref(ms)))
+        return words, anym, ms.value
+
+    def counts(self):
+        L, h = self.lib, self.h
+        return dict(nprimal=L.bslv_poly_nprimal(h), ndual=L.bslv_poly_ndual(h), nedges=L.bslv_poly_nedges(h),
+                    pair_tests=L.bslv_poly_pair_tests(h), new_vertices=L.bslv_poly_new_vertices(h))
+
+    def dump(self):
+        L, h, d = self.lib, self.h, self.d
+        nv, nf = L.bslv_poly_nprimal(h), L.bslv_poly_ndual(h)
+        pu, pi, ps = (np.zeros(nv, np.uint8) for _ in range(3))
+        X = np.zeros((nv, d))
+        check(L.bslv_poly_get_primal(h, pu.ctypes.data, pi.ctypes.data, ps.ctypes.data, X.ctypes.data))
+        du, di = np.zeros(nf, np.uint8), np.zeros(nf, np.uint8)
+        Y = np.zeros((nf, d))
+        check(L.bslv_poly_get_dual(h, du.ctypes.data, di.ctypes.data, Y.ctypes.data))
+        E = np.zeros((L.bslv_poly_nedges(h), 2), np.int32)
+        check(L.bslv_poly_get_edges(h, E.ctypes.data))
+        I = np.zeros((L.bslv_poly_ninc(h), 2), np.int32)
+        check(L.bslv_poly_get_inc(h, I.ctypes.data))
+        DE = np.zeros((L.bslv_poly_ndual_edges(h), 2), np.int32)
+        check(L.bslv_poly_get_dual_edges(h, DE.ctypes.data))
+        return dict(d=d, pu=pu, pi=pi, ps=ps, X=X, du=du, di=di, Y=Y, E=E, I=I, DE=DE)

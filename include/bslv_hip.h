@@ -86,6 +86,50 @@ int  bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out);
 int  bslv_lpq_set_profile(bslv_lpq *h, int on);
 int  bslv_lpq_last_stats(const bslv_lpq *h, int *lockstep_iters, long *pivots, double *update_ms, double *total_ms);
 
+/* ------------------------------------------------------------------------------------------
+ * 2. Polyhedron engine  (replaces bslv_poly.h:90-118)
+ *
+ * Same object as the reference's poly_args: a primal polyhedron (points + directions) and its
+ * dual (one dual vertex per halfspace); `val`/`ideal` arguments are what the reference passes in
+ * poly_args.val / poly_args.ideal.  v2h selects the dualV2primalH callback (a function pointer
+ * without context in the reference, bslv_poly.h:79-80):
+ *   0 cone_polar (bslv_poly.c:30-39)  1 lowerV2upperH (bslv_algs.c:287-305, parameter c)
+ *   2 upperV2lowerH (bslv_algs.c:307-313, parameter c)
+ * rc_out follows the reference's EXIT_SUCCESS(0) / EXIT_FAILURE(1) convention.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bslv_poly bslv_poly;
+
+int  bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c /* dim, may be NULL */);
+                                                              /* poly__set_default_args + poly__initialise :41-102 */
+void bslv_poly_destroy(bslv_poly *h);                         /* poly__kill :258 */
+int  bslv_poly_dual0_apex(bslv_poly *h);                      /* cone_vertenum's tweak, bslv_algs.c:338-339 */
+int  bslv_poly_add(bslv_poly *h, const double *val, int ideal, int *rc_out);       /* poly__add_vrtx :104 */
+int  bslv_poly_add_cuts(bslv_poly *h, int B, const double *val /* B*dim */, const int *ideal /* may be NULL */,
+                        int *rc_out /* B */);                 /* batched poly__add_vrtx */
+int  bslv_poly_init(bslv_poly *h, int *rc_out);               /* poly__intl_apprx :153 */
+int  bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out); /* poly__get_vrtx :210 */
+int  bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count);
+int  bslv_poly_mark(bslv_poly *h, int n, const int *idx);     /* ST_BT(primal.sltn, idx) */
+int  bslv_poly_dual_adjacency(bslv_poly *h);                  /* poly__update_adjacence(&dual) :992 */
+/* batched incidence kernel on the current elements: hps = B x (dim+1) halfspaces (normal, alpha);
+ * words_out: ceil(B/32) x nprimal 64-bit words, 2 bits per class (0 dead 1 MINUS 2 ZERO 3 PLUS) */
+int  bslv_poly_classify_batch(bslv_poly *h, int B, const double *hps, unsigned long long *words_out,
+                              int *anyminus_out, int repeats, float *ms_out);
+/* counts and slot-indexed dumps (poly__vrtx2file / adj2file / inc2file write these, :341-414) */
+int  bslv_poly_dim(const bslv_poly *h);
+int  bslv_poly_nprimal(const bslv_poly *h);
+int  bslv_poly_ndual(const bslv_poly *h);
+long bslv_poly_nedges(const bslv_poly *h);
+long bslv_poly_ninc(bslv_poly *h);
+long bslv_poly_ndual_edges(const bslv_poly *h);
+long bslv_poly_pair_tests(const bslv_poly *h);
+long bslv_poly_new_vertices(const bslv_poly *h);
+int  bslv_poly_get_primal(bslv_poly *h, unsigned char *used, unsigned char *ideal, unsigned char *sltn, double *coords);
+int  bslv_poly_get_dual(bslv_poly *h, unsigned char *used, unsigned char *ideal, double *coords);
+int  bslv_poly_get_edges(bslv_poly *h, int *ab);
+int  bslv_poly_get_inc(bslv_poly *h, int *pairs);
+int  bslv_poly_get_dual_edges(bslv_poly *h, int *ab);
+
 #ifdef __cplusplus
 }
 #endif
