@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's phase-2 driver (bslv_algs.c:958-1082) over the batched engine.
+
+Single process: `BensonEngine.step()`.  Multi-GPU: one process per GPU, `step_distributed()` does
+collect -> solve_local -> ONE all_gather of the fixed-size cut records (torch.distributed; backend
+"nccl" = RCCL on GPU, "gloo" in the CPU tests) -> apply on every rank."""
+import ctypes
+import numpy as np
+from ._lib import load_library, check
+from .poly import PolyEngine, _bind as _bind_poly
+from .lp import LpEngine
+
+_bound = False
+
+
+def _bind(lib):
+    global _bound
+    if _bound:
+        return
+    vp, i, d = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.bslv_benson_create.argtypes = [ctypes.POINTER(vp), i, i, i] + [vp] * 8 + [vp, i, vp, d, i]
+    lib.bslv_benson_destroy.argtypes = [vp]
+    lib.bslv_benson_destroy.restype = None
+    lib.bslv_benson_start.argtypes = [vp, vp]
+    lib.bslv_benson_collect.argtypes = [vp, i, i, i, vp, vp]
+    lib.bslv_benson_record_len.argtypes = [vp]
+    lib.bslv_benson_solve_local.argtypes = [vp, vp, vp, vp]
+    lib.bslv_benson_apply.argtypes = [vp, i, vp, vp]
+    lib.bslv_benson_step.argtypes = [vp, i, vp, vp]
+    lib.bslv_benson_unprocessed_left.argtypes = [vp]
+    lib.bslv_benson_totals.argtypes = [vp, vp, vp, vp]
+    lib.bslv_benson_poly.argtypes = [vp]
+    lib.bslv_benson_poly.restype = vp
+    lib.bslv_benson_lp.argtypes = [vp]
+    lib.bslv_benson_lp.restype = vp
+    _bound = True
+
+
+class BensonEngine:
+    def __init__(self, prob, R=None, c=None, eps=1e-7, pool_slots=256):
+        self.lib = load_library()
+        _bind(self.lib)
+        _bind_poly(self.lib)
+        m, n, q = prob["m"], prob["n"], prob["q"]
+        self.q = q
+        f8 = lambda a: np.ascontiguousarray(a, np.float64)
+        A, P = f8(prob["A"]), f8(prob["P"])
+        R = np.eye(q) if R is None else f8(R)
+        c = np.ones(q) if c is None else f8(c)
+        rt = np.ascontiguousarray(prob["rtype"], np.uint8)
+        ct = np.ascontiguousarray(prob["ctype"], np.uint8)
+        rlb, rub, clb, cub = f8(prob["rlb"]), f8(prob["rub"]), f8(prob["clb"]), f8(prob["cub"])
+        h = ctypes.c_void_p()
+        check(self.lib.bslv_benson_create(ctypes.byref(h), m, n, q, A.ctypes.data, P.ctypes.data, rt.ctypes.data,
+                                          rlb.ctypes.data, rub.ctypes.data, ct.ctypes.data, clb.ctypes.data, cub.ctypes.data,
+                                          R.ctypes.data, R.shape[1], c.ctypes.data, eps, pool_slots))
+        self.h = h
+        self.rec_len = self.lib.bslv_benson_record_len(h)
+        # non-owning views of the two engines (for dumps / stats)
+        self.poly = PolyEngine.__new__(PolyEngine)
+        self.poly.lib, self.poly.d, self.poly.h = self.lib, q, None
+        self._poly_h = ctypes.c_void_p(self.lib.bslv_benson_poly(h))
+        self.lp = LpEngine.__new__(LpEngine)
+        self.lp.lib, self.lp.h = self.lib, None
+        self._lp_h = ctypes.c_void_p(self.lib.bslv_benson_lp(h))
+
+    # views that do not destroy the borrowed handles
+    def poly_dump(self):
+        self.poly.h = self._poly_h
+        try:
+            return self.poly.dump()
+        finally:
+            self.poly.h = None
+
+    def poly_call(self, name, *a):
+        self.poly.h = self._poly_h
+        try:
+            return getattr(self.poly, name)(*a)
+        finally:
+            self.poly.h = None
+
+    def lp_call(self, name, *a):
+        self.lp.h = self._lp_h
+        try:
+            return getattr(self.lp, name)(*a)
+        finally:
+            self.lp.h = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bslv_benson_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def start(self):
+        st = ctypes.c_int()
+        check(self.lib.bslv_benson_start(self.h, ctypes.byref(st)))
+        return st.value
+
+    def step(self, max_batch):
+        stats = (ctypes.c_long * 8)()
+        ms = (ctypes.c_double * 3)()
+        check(self.lib.bslv_benson_step(self.h, max_batch, stats, ms))
+        keys = ("lps", "cuts", "redundant", "confirmed", "failed", "pivots", "lockstep", "left")
+        out = dict(zip(keys, list(stats)))
+        out.update(ms_lp=ms[0], ms_poly=ms[1], ms_total=ms[2])
+        return out
+
+    def collect(self, max_batch, rank=0, world=1):
+        nl, nt = ctypes.c_int(), ctypes.c_int()
+        check(self.lib.bslv_benson_collect(self.h, max_batch, rank, world, ctypes.byref(nl), ctypes.byref(nt)))
+        return nl.value, nt.value
+
+    def solve_local(self, n_local):
+        rec = np.zeros((max(n_local, 1), self.rec_len))
+        piv, ls = ctypes.c_int(), ctypes.c_int()
+        check(self.lib.bslv_benson_solve_local(self.h, rec.ctypes.data, ctypes.byref(piv), ctypes.byref(ls)))
+        return rec[:n_local], piv.value, ls.value
+
+    def apply(self, records):
+        records = np.ascontiguousarray(records, np.float64).reshape(-1, self.rec_len)
+        stats = (ctypes.c_long * 5)()
+        check(self.lib.bslv_benson_apply(self.h, len(records), records.ctypes.data, stats))
+        return dict(zip(("lps", "cuts", "redundant", "confirmed", "failed"), list(stats)))
+
+    def totals(self):
+        a, b, c = ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
+        check(self.lib.bslv_benson_totals(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return dict(lps=a.value, cuts=b.value, pivots=c.value)
+
+    def run(self, max_batch, max_steps=None):
+        """run to termination (poly__get_vrtx returns 'none left', bslv_algs.c:1032-1035)"""
+        steps = 0
+        while max_steps is None or steps < max_steps:
+            s = self.step(max_batch)
+            steps += 1
+            if s["lps"] == 0 and s["left"] == 0:
+                break
+        return steps
+
+    def step_distributed(self, max_batch, dist, device):
+        """one outer iteration over all ranks of `dist` (torch.distributed): the batch is dealt to
+        ranks, each solves its shard, ONE all_gather of the padded record blocks, all apply."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        n_local, n_total = self.collect(max_batch, rank, world)
+        rec, piv, ls = self.solve_local(n_local)
+        cap = (n_total + world - 1) // world + max(1, n_total // (4 * world)) + 1
+        block = torch.zeros((cap + 1, self.rec_len), dtype=torch.float64)
+        block[0, 0] = n_local
+        if n_local:
+            block[1:1 + n_local] = torch.from_numpy(rec)
+        block = block.to(device)
+        gathered = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(gathered, block)
+        parts = []
+        for g in gathered:
+            g = g.cpu().numpy()
+            parts.append(g[1:1 + int(g[0, 0])])
+        allrec = np.concatenate(parts, axis=0) if parts else np.zeros((0, self.rec_len))
+        st = self.apply(allrec)
+        st.update(n_local=n_local, n_total=n_total, pivots=piv, lockstep=ls)
+        return st

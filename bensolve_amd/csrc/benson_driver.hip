@@ -1,0 +1,375 @@
+// benson_driver.hip -- host side of the re-shaped hot loop: phase2_primal (bslv_algs.c:958-1082)
+// turned from "one vertex -> one LP -> one cut" into
+//     collect unprocessed vertices -> batched LPs (lp_engine) -> gather cut records -> apply cuts
+// (poly_engine).  Pure host code (no kernels here); the two engines own the device work.
+//
+// Multi-GPU: every rank holds a replica of the polyhedron and the same vertex
+// list; collect() deals the batch to ranks (affinity to the rank that holds the parent tableau,
+// else least loaded), each rank solves its shard, the fixed-size records are all-gathered by the
+// caller (RCCL, one collective per outer iteration) and every rank applies ALL records in
+// ascending source-slot order, so the replicas stay identical without further traffic.
+#include "common.h"
+#include <vector>
+#include <algorithm>
+#include <chrono>
+#include <deque>
+#include <unordered_map>
+
+extern "C" {
+int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
+}
+
+using namespace bslv;
+using clk = std::chrono::steady_clock;
+static double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+struct bslv_benson {
+    int m = 0, n = 0, q = 0, r = 0, M = 0, N = 0;
+    double eps = 1e-7;
+    std::vector<double> R, c;           // q x r (generators as columns), q
+    bslv_lpq *lp = nullptr;
+    bslv_poly *poly = nullptr;
+    int pool_slots = 0;
+    // tableau slots: 0 = root (kept).  facet -> slot of the LP that produced the cut
+    std::vector<int> free_slots;
+    std::deque<std::pair<int, int>> parents;          // (facet, slot) in creation order
+    std::unordered_map<int, int> facet_slot;
+    std::vector<int> facet_owner;                     // by facet id: rank that solved its LP (-1 unknown)
+    bool started = false;
+    // current batch (after collect)
+    std::vector<int> b_idx, b_parent, b_owner;        // whole batch (all ranks)
+    std::vector<double> b_val;
+    std::vector<int> l_pos, l_slot;                   // local shard: position in batch, dst slot
+    int rank = 0, world = 1;
+    int unprocessed_left = 0;
+    // totals
+    long tot_lps = 0, tot_cuts = 0, tot_pivots = 0;
+};
+
+static int rec_len(const bslv_benson *h) { return h->q + 5; }
+
+extern "C" {
+
+int bslv_benson_record_len(const bslv_benson *h) { return h ? rec_len(h) : 0; }
+bslv_poly *bslv_benson_poly(bslv_benson *h) { return h ? h->poly : nullptr; }
+bslv_lpq *bslv_benson_lp(bslv_benson *h) { return h ? h->lp : nullptr; }
+
+void bslv_benson_destroy(bslv_benson *h)
+{
+    if (!h) return;
+    if (h->lp) bslv_lpq_destroy(h->lp);
+    if (h->poly) bslv_poly_destroy(h->poly);
+    delete h;
+}
+
+static void bounds_of(char t, double lb, double ub, double *lo, double *up)
+{
+    // 'f','l','u','d','s' -> [lo,up]  (bslv_lp.c:34-43; 's' fixes at lb)
+    *lo = (t == 'l' || t == 'd' || t == 's') ? lb : -INFINITY;
+    *up = (t == 'u' || t == 'd') ? ub : (t == 's' ? lb : INFINITY);
+}
+
+// Problem in the reference's normal form "min, c_q > 0" (sol_init has already flipped P for
+// max / c_q < 0, bslv_vlp.c:845-861).  R: q x r, generators as columns (bslv_algs.c:599).
+int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, const double *P,
+                       const char *rtype, const double *rlb, const double *rub,
+                       const char *ctype, const double *clb, const double *cub,
+                       const double *R, int r, const double *c, double eps, int pool_slots)
+{
+    if (!out || m < 1 || n < 1 || q < 2 || r < 1 || !A || !P || !rtype || !ctype || !R || !c || pool_slots < 4) {
+        set_error("bslv_benson_create: bad argument");
+        return BSLV_E_ARG;
+    }
+    bslv_benson *h = new bslv_benson();
+    h->m = m; h->n = n; h->q = q; h->r = r; h->eps = eps;
+    h->R.assign(R, R + (size_t)q * r);
+    h->c.assign(c, c + q);
+    // init_P2 (bslv_algs.c:574-664), inhomogeneous: rows m (A x), q (-P x + y = 0), r (R_j.y - z <= ub_j),
+    // 1 free eta row; cols n (x), q (y free), 1 (z free, cost 1)
+    const int M = m + q + r + 1, N = n + q + 1;
+    h->M = M; h->N = N;
+    std::vector<double> L((size_t)M * N, 0.0), lo(M + N), up(M + N), cost(N + 1, 0.0);
+    for (int i = 0; i < m; i++) memcpy(&L[(size_t)i * N], A + (size_t)i * n, n * sizeof(double));
+    for (int k = 0; k < q; k++) {
+        for (int j = 0; j < n; j++) L[(size_t)(m + k) * N + j] = -P[(size_t)k * n + j];
+        L[(size_t)(m + k) * N + n + k] = 1.0;
+    }
+    for (int i = 0; i < r; i++) {
+        for (int k = 0; k < q; k++) L[(size_t)(m + q + i) * N + n + k] = R[(size_t)k * r + i];
+        L[(size_t)(m + q + i) * N + n + q] = -1.0;
+    }
+    for (int i = 0; i < m; i++) bounds_of(rtype[i], rlb ? rlb[i] : 0, rub ? rub[i] : 0, &lo[i], &up[i]);
+    for (int k = 0; k < q; k++) { lo[m + k] = 0; up[m + k] = 0; }
+    for (int i = 0; i < r; i++) { lo[m + q + i] = -INFINITY; up[m + q + i] = 0; }
+    lo[m + q + r] = -INFINITY; up[m + q + r] = INFINITY;
+    for (int j = 0; j < n; j++) bounds_of(ctype[j], clb ? clb[j] : 0, cub ? cub[j] : 0, &lo[M + j], &up[M + j]);
+    for (int j = n; j < N; j++) { lo[M + j] = -INFINITY; up[M + j] = INFINITY; }
+    cost[N] = 1.0;
+    int rc = bslv_lpq_create(&h->lp, M, N, L.data(), lo.data(), up.data(), cost.data(), m + q, r, pool_slots);
+    if (rc) { bslv_benson_destroy(h); return rc; }
+    rc = bslv_poly_create(&h->poly, q, 1 /* lowerV2upperH */, c);
+    if (rc) { bslv_benson_destroy(h); return rc; }
+    h->pool_slots = pool_slots;
+    for (int s = pool_slots - 1; s >= 1; s--) h->free_slots.push_back(s);
+    *out = h;
+    return 0;
+}
+
+// PART 1 of phase2_primal (bslv_algs.c:976-1018): r weighted-sum LPs from a cold start, then the
+// initial outer approximation.  *vlp_status: 0 ok, 1 infeasible, 2 unbounded.
+int bslv_benson_start(bslv_benson *h, int *vlp_status)
+{
+    if (!h || !vlp_status) return BSLV_E_ARG;
+    const int q = h->q, r = h->r;
+    int rc;
+    *vlp_status = 0;
+    if ((rc = bslv_lpq_reset_slot(h->lp, 0))) return rc;
+    std::vector<double> vlo(r, -INFINITY), vup(r), val(q);
+    const int zero = 0;
+    for (int j = 0; j < r; j++) {
+        for (int i = 0; i < r; i++) vup[i] = (i == j) ? 0.0 : INFINITY;     // row j 'u' (ub 0), others 'f'
+        int st, it;
+        // each weighted-sum LP starts cold: freeing row j-1 leaves the previous basis dual infeasible,
+        // which the dual-only engine reports as UNDEFINED (GLPK would switch to its primal phase)
+        if (j > 0 && (rc = bslv_lpq_reset_slot(h->lp, 0))) return rc;
+        if ((rc = bslv_lpq_solve_batch(h->lp, 1, &zero, &zero, vlo.data(), vup.data(), &st, &it))) return rc;
+        h->tot_pivots += it;
+        if (st != BSLV_LP_OPTIMAL) { *vlp_status = (st == BSLV_LP_INFEASIBLE) ? 1 : 2; return 0; }
+        h->tot_lps++;
+        double obj;
+        if ((rc = bslv_lpq_get_obj(h->lp, 1, &zero, &obj))) return rc;
+        for (int k = 0; k < q; k++) val[k] = h->R[(size_t)k * r + j];
+        val[q - 1] = obj;
+        int prc;
+        if ((rc = bslv_poly_add(h->poly, val.data(), 0, &prc))) return rc;
+    }
+    int irc;
+    if ((rc = bslv_poly_init(h->poly, &irc))) return rc;
+    if (irc) { set_error("initial outer approximation failed (rank-deficient start, bslv_poly.c:174)"); return BSLV_E_STATE; }
+    h->facet_owner.assign(bslv_poly_ndual(h->poly), -1);
+    h->started = true;
+    return 0;
+}
+
+// Select the next batch (the newest max_batch unprocessed elements; directions are only marked,
+// bslv_algs.c:1036-1040) and deal it to ranks.  n_local = LPs this rank will solve.
+int bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int *n_local, int *n_total)
+{
+    if (!h || !h->started || max_batch < 1 || world < 1 || rank < 0 || rank >= world || !n_local || !n_total) {
+        set_error("bslv_benson_collect: bad argument / not started");
+        return BSLV_E_ARG;
+    }
+    const int q = h->q;
+    h->rank = rank; h->world = world;
+    int rc, cnt = 0;
+    for (;;) {
+        if ((rc = bslv_poly_unprocessed2(h->poly, 0, 1, nullptr, nullptr, nullptr, nullptr, &cnt))) return rc;
+        int nb = std::min(cnt, max_batch);
+        std::vector<int> idx(nb), ideal(nb), parent(nb);
+        std::vector<double> val((size_t)nb * q);
+        if (nb && (rc = bslv_poly_unprocessed2(h->poly, nb, 1, idx.data(), val.data(), ideal.data(), parent.data(), &cnt))) return rc;
+        std::vector<int> dirs;
+        h->b_idx.clear(); h->b_val.clear(); h->b_parent.clear();
+        for (int k = 0; k < nb; k++) {
+            if (ideal[k]) { dirs.push_back(idx[k]); continue; }
+            h->b_idx.push_back(idx[k]);
+            h->b_parent.push_back(parent[k]);
+            h->b_val.insert(h->b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
+        }
+        if (!dirs.empty() && (rc = bslv_poly_mark(h->poly, (int)dirs.size(), dirs.data()))) return rc;
+        h->unprocessed_left = cnt - nb;
+        if (!h->b_idx.empty() || dirs.empty()) break;     // only directions in this window: look again
+    }
+    const int nb = (int)h->b_idx.size();
+    // deal to ranks: owner of the parent cut if known and not overloaded, else least loaded
+    h->b_owner.assign(nb, 0);
+    std::vector<int> load(world, 0);
+    const int cap = (nb + world - 1) / world + std::max(1, nb / (4 * world));
+    for (int k = 0; k < nb; k++) {
+        int f = h->b_parent[k];
+        int o = (f >= 0 && f < (int)h->facet_owner.size()) ? h->facet_owner[f] : -1;
+        if (o < 0 || o >= world || load[o] >= cap) o = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        h->b_owner[k] = o;
+        load[o]++;
+    }
+    h->l_pos.clear();
+    for (int k = 0; k < nb; k++) if (h->b_owner[k] == rank) h->l_pos.push_back(k);
+    *n_local = (int)h->l_pos.size();
+    *n_total = nb;
+    return 0;
+}
+
+static int take_slot(bslv_benson *h)
+{
+    if (h->free_slots.empty()) {
+        // evict the oldest parents (FIFO); their children fall back to the root tableau
+        int want = std::max(1, h->pool_slots / 8);
+        while (want-- > 0 && !h->parents.empty()) {
+            auto pr = h->parents.front();
+            h->parents.pop_front();
+            auto it = h->facet_slot.find(pr.first);
+            if (it != h->facet_slot.end() && it->second == pr.second) { h->facet_slot.erase(it); h->free_slots.push_back(pr.second); }
+        }
+        if (h->free_slots.empty()) return -1;
+    }
+    int s = h->free_slots.back();
+    h->free_slots.pop_back();
+    return s;
+}
+
+// Solve this rank's shard.  records: n_local x (q+5) doubles
+//   [source slot, LP status, add (z > eps), z, y*_1..y*_q, owner rank]   
+int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, int *lockstep_out)
+{
+    if (!h || !h->started) { set_error("bslv_benson_solve_local: not started"); return BSLV_E_STATE; }
+    const int q = h->q, r = h->r, nl = (int)h->l_pos.size(), RL = rec_len(h);
+    if (pivots_out) *pivots_out = 0;
+    if (lockstep_out) *lockstep_out = 0;
+    if (nl == 0) return 0;
+    if (!records) return BSLV_E_ARG;
+    if (nl > h->pool_slots - 1) { set_error("batch shard (%d) larger than the tableau pool (%d)", nl, h->pool_slots - 1); return BSLV_E_CAPACITY; }
+    std::vector<int> src(nl), dst(nl);
+    std::vector<double> vlo((size_t)nl * r, -INFINITY), vup((size_t)nl * r);
+    h->l_slot.assign(nl, -1);
+    // sources first (eviction below must not take a slot we are about to read)
+    for (int k = 0; k < nl; k++) {
+        int f = h->b_parent[h->l_pos[k]];
+        auto it = h->facet_slot.find(f);
+        src[k] = (it != h->facet_slot.end()) ? it->second : 0;
+    }
+    std::vector<char> is_src(h->pool_slots, 0);
+    for (int k = 0; k < nl; k++) is_src[src[k]] = 1;
+    for (int k = 0; k < nl; k++) {
+        int s = -1;
+        for (int tries = 0; tries < h->pool_slots + 8; tries++) {
+            s = take_slot(h);
+            if (s < 0) break;
+            if (!is_src[s]) break;
+            // an evicted parent that is still a source of this batch: keep it alive for this batch
+            h->parents.emplace_back(-2, s);
+            s = -1;
+        }
+        if (s < 0) { set_error("tableau pool exhausted (%d slots)", h->pool_slots); return BSLV_E_NOMEM; }
+        dst[k] = s;
+        h->l_slot[k] = s;
+        const double *v = &h->b_val[(size_t)h->l_pos[k] * q];
+        for (int j = 0; j < r; j++) {                   // rows->ub[j] = R_j . v   (bslv_algs.c:1041-1046)
+            double ub = 0;
+            for (int kk = 0; kk < q; kk++) ub += h->R[(size_t)kk * r + j] * v[kk];
+            vup[(size_t)k * r + j] = ub;
+        }
+    }
+    std::vector<int> st(nl), it(nl);
+    int rc;
+    if ((rc = bslv_lpq_solve_batch(h->lp, nl, src.data(), dst.data(), vlo.data(), vup.data(), st.data(), it.data()))) return rc;
+    std::vector<double> ww((size_t)nl * q), yy((size_t)nl * q), zz(nl);
+    if ((rc = bslv_lpq_get_dual(h->lp, nl, dst.data(), h->m, q, ww.data()))) return rc;                 // bslv_algs.c:1050
+    if ((rc = bslv_lpq_get_primal(h->lp, nl, dst.data(), h->M + h->n, q, yy.data()))) return rc;        // :1055
+    if ((rc = bslv_lpq_get_obj(h->lp, nl, dst.data(), zz.data()))) return rc;                           // :1056
+    long piv = 0;
+    for (int k = 0; k < nl; k++) {
+        double *rec = records + (size_t)k * RL;
+        rec[0] = h->b_idx[h->l_pos[k]];
+        rec[1] = st[k];
+        rec[3] = zz[k];
+        double last = 0;
+        for (int kk = 0; kk < q - 1; kk++) rec[4 + kk] = ww[(size_t)k * q + kk];
+        for (int kk = 0; kk < q; kk++) last += yy[(size_t)k * q + kk] * ww[(size_t)k * q + kk];         // y*_q = w.Px (:1059-1062)
+        rec[4 + q - 1] = last;
+        rec[2] = (st[k] == BSLV_LP_OPTIMAL && zz[k] > h->eps) ? 1.0 : 0.0;                              // :1063
+        rec[4 + q] = h->rank;
+        piv += it[k];
+    }
+    h->tot_pivots += piv;
+    if (pivots_out) *pivots_out = (int)piv;
+    int ls = 0;
+    bslv_lpq_last_stats(h->lp, &ls, nullptr, nullptr, nullptr);
+    if (lockstep_out) *lockstep_out = ls;
+    return 0;
+}
+
+// Apply ALL ranks' records (any order in; applied in ascending source slot).  stats (may be NULL):
+// [0] LPs, [1] cuts applied, [2] redundant cuts, [3] confirmed vertices, [4] LP failures
+int bslv_benson_apply(bslv_benson *h, int nrec, const double *records, long *stats)
+{
+    if (!h || !h->started || nrec < 0 || (nrec > 0 && !records)) return BSLV_E_ARG;
+    const int q = h->q, RL = rec_len(h);
+    std::vector<int> order(nrec);
+    for (int k = 0; k < nrec; k++) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return records[(size_t)a * RL] < records[(size_t)b * RL]; });
+    std::vector<int> confirmed, cut_src;
+    std::vector<double> cuts;
+    long nfail = 0;
+    for (int k : order) {
+        const double *rec = records + (size_t)k * RL;
+        if ((int)rec[1] != BSLV_LP_OPTIMAL) { nfail++; continue; }
+        if (rec[2] != 0.0) { cuts.insert(cuts.end(), rec + 4, rec + 4 + q); cut_src.push_back(k); }
+        else confirmed.push_back((int)rec[0]);                                                           // :1074-1079
+    }
+    int rc;
+    if (nfail) { set_error("%ld LP(s) of the batch did not reach optimality (the reference asserts here, bslv_algs.c:1049)", nfail); return BSLV_E_STATE; }
+    if (!confirmed.empty() && (rc = bslv_poly_mark(h->poly, (int)confirmed.size(), confirmed.data()))) return rc;
+    const int ncut = (int)cut_src.size();
+    std::vector<int> prc(ncut, 0);
+    const int f0 = bslv_poly_ndual(h->poly);
+    if (ncut && (rc = bslv_poly_add_cuts(h->poly, ncut, cuts.data(), nullptr, prc.data()))) return rc;
+    // bookkeeping: facet ids f0.. were assigned in this order on every rank
+    h->facet_owner.resize(f0 + ncut, -1);
+    long applied = 0;
+    // local slot of a record: position in this rank's shard
+    std::unordered_map<int, int> slot_of_src;
+    for (size_t k = 0; k < h->l_pos.size(); k++) slot_of_src[h->b_idx[h->l_pos[k]]] = h->l_slot[k];
+    for (int c = 0; c < ncut; c++) {
+        const double *rec = records + (size_t)cut_src[c] * RL;
+        const int owner = (int)rec[4 + q], f = f0 + c;
+        h->facet_owner[f] = owner;
+        if (prc[c] == 0) applied++;
+        if (owner == h->rank) {
+            auto it = slot_of_src.find((int)rec[0]);
+            if (it != slot_of_src.end()) {
+                if (prc[c] == 0) { h->facet_slot[f] = it->second; h->parents.emplace_back(f, it->second); }
+                else h->free_slots.push_back(it->second);
+                slot_of_src.erase(it);
+            }
+        }
+    }
+    for (auto &kv : slot_of_src) h->free_slots.push_back(kv.second);    // confirmed vertices: tableau not needed again
+    h->l_pos.clear(); h->l_slot.clear();
+    h->tot_lps += nrec;
+    h->tot_cuts += applied;
+    if (stats) { stats[0] = nrec; stats[1] = applied; stats[2] = ncut - applied; stats[3] = (long)confirmed.size(); stats[4] = nfail; }
+    return 0;
+}
+
+// single-process outer iteration.  stats: as bslv_benson_apply, plus [5] pivots, [6] lock-step
+// iterations, [7] unprocessed elements left; ms: [0] LP, [1] poly, [2] total
+int bslv_benson_step(bslv_benson *h, int max_batch, long *stats, double *ms)
+{
+    if (!h) return BSLV_E_ARG;
+    auto t0 = clk::now();
+    int nl = 0, nt = 0, rc;
+    if ((rc = bslv_benson_collect(h, max_batch, 0, 1, &nl, &nt))) return rc;
+    auto t1 = clk::now();
+    std::vector<double> rec((size_t)std::max(1, nl) * rec_len(h));
+    int piv = 0, ls = 0;
+    if ((rc = bslv_benson_solve_local(h, rec.data(), &piv, &ls))) return rc;
+    double ms_lp = ms_since(t1);
+    auto t2 = clk::now();
+    long st[5] = {0, 0, 0, 0, 0};
+    if ((rc = bslv_benson_apply(h, nl, rec.data(), st))) return rc;
+    if (stats) { for (int k = 0; k < 5; k++) stats[k] = st[k]; stats[5] = piv; stats[6] = ls; stats[7] = h->unprocessed_left; }
+    if (ms) { ms[0] = ms_lp; ms[1] = ms_since(t2) + std::chrono::duration<double, std::milli>(t1 - t0).count(); ms[2] = ms_since(t0); }
+    return 0;
+}
+
+int bslv_benson_unprocessed_left(const bslv_benson *h) { return h ? h->unprocessed_left : 0; }
+int bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots)
+{
+    if (!h) return BSLV_E_ARG;
+    if (lps) *lps = h->tot_lps;
+    if (cuts) *cuts = h->tot_cuts;
+    if (pivots) *pivots = h->tot_pivots;
+    return 0;
+}
+
+}  // extern "C"

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
         for (int i = threadIdx.x; i < L.M; i += NT) bh_d[i] = bh_s[i];
         for (int i = threadIdx.x; i < L.M + L.N; i += NT) pos_d[i] = pos_s[i];
     }
+    int dual_infeasible = 0;
     for (int j = threadIdx.x; j < L.ld; j += NT) {
         if (j >= L.N) { xN_d[j] = 0.0; continue; }
         int k = nh_s[j];
@@ -101,12 +102,19 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
             else if (dj > TOL_DJ) st = NS_L;
             else if (st != NS_L && st != NS_U) st = NS_L;
         }
+        // the dual simplex needs a dual feasible start: a bound that vanished under a non-zero
+        // reduced cost cannot be repaired by a flip (the reference's GLPK would run its primal phase)
+        {
+            double dj = drow_s[j];
+            if ((st == NS_F && fabs(dj) > 1e-7) || (st == NS_L && dj < -1e-7) || (st == NS_U && dj > 1e-7)) dual_infeasible = 1;
+        }
         nh_d[j] = k;
         ns_d[j] = st;
         xN_d[j] = (st == NS_F) ? 0.0 : (st == NS_U ? up : lo);
     }
+    dual_infeasible = __syncthreads_or(dual_infeasible);
     if (threadIdx.x == 0) {
-        Bv.status[b] = ST_RUNNING;
+        Bv.status[b] = dual_infeasible ? BSLV_LP_UNDEFINED : ST_RUNNING;
         Bv.iters[b] = 0;
         Bv.mode[b] = MODE_NONE;
         Bv.verified[b] = 1;   // k_init recomputes beta from scratch

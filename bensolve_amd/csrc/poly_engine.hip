@@ -428,7 +428,8 @@ __global__ __launch_bounds__(PB) void k_unproc_flags(PolyView P, int nv, Tri *bs
     (void)block_exscan(t, &tot, lds);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(PB) void k_unproc_emit(PolyView P, int nv, const Tri *bpre, int maxout, int *idx, double *val, unsigned char *fl_out)
+__global__ __launch_bounds__(PB) void k_unproc_emit(PolyView P, int nv, const Tri *bpre, int skip, int maxout, int *idx, double *val,
+                                                     unsigned char *fl_out, int *parent)
 {
     __shared__ Tri lds[16];
     int i = blockIdx.x * PB + threadIdx.x;
@@ -438,10 +439,11 @@ __global__ __launch_bounds__(PB) void k_unproc_emit(PolyView P, int nv, const Tr
     Tri tot;
     Tri ex = block_exscan(t, &tot, lds);
     if (i >= nv || !t.a) return;
-    int pos = bpre[blockIdx.x].a + ex.a;
-    if (pos >= maxout) return;
+    int pos = bpre[blockIdx.x].a + ex.a - skip;
+    if (pos < 0 || pos >= maxout) return;
     idx[pos] = i;
     fl_out[pos] = fl;
+    parent[pos] = P.inc_len[i] > 0 ? P.pool[P.inc_off[i] + P.inc_len[i] - 1] : -1;   // newest facet through it
     for (int k = 0; k < P.d; k++) val[(size_t)pos * P.d + k] = P.X[(size_t)k * P.cap + i];
 }
 __global__ void k_mark(PolyView P, const int *idx, int n, unsigned char bit)
@@ -560,6 +562,7 @@ struct bslv_poly {
     unsigned long long *clsw = nullptr; size_t clswcap = 0;
     int *anyminus = nullptr; int anycap = 0;
     int *idx_d = nullptr; double *val_d = nullptr; unsigned char *fl_d = nullptr; int outcap = 0;
+    int *par_d = nullptr; int parcap = 0;
 };
 
 static void v2h_map(const bslv_poly *h, const double *v, int is_dir, double *hp)
@@ -844,7 +847,7 @@ void bslv_poly_destroy(bslv_poly *h)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters);
-    fr(h->blks); fr(h->pflag); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d);
+    fr(h->blks); fr(h->pflag); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->totals_h) (void)hipHostFree(h->totals_h);
     if (h->counters_h) (void)hipHostFree(h->counters_h);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1017,7 +1020,14 @@ int bslv_poly_classify_batch(bslv_poly *h, int B, const double *hps, unsigned lo
 
 // all unprocessed elements (used && !sltn) in ascending slot order: the set poly__get_vrtx
 // iterates (bslv_poly.c:214-216).  *count = how many exist; at most max_out are written.
+int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
 int bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count)
+{
+    return bslv_poly_unprocessed2(h, max_out, 0, idx, val, ideal, nullptr, count);
+}
+// from_end != 0: the max_out NEWEST unprocessed elements (highest slots); parent[k] = newest facet
+// through element k (the cut that created it), -1 if none
+int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count)
 {
     if (!h || !count || max_out < 0) { set_error("bslv_poly_unprocessed: bad argument"); return BSLV_E_ARG; }
     *count = 0;
@@ -1038,9 +1048,12 @@ int bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int 
         if ((rc = grow(&h->fl_d, 0, (size_t)nc, h->stream))) return rc;
         h->outcap = nc;
     }
-    hipLaunchKernelGGL(k_unproc_emit, dim3(nb), dim3(PB), 0, h->stream, h->P, nv, h->bsum, n, h->idx_d, h->val_d, h->fl_d);
+    if (n > h->parcap) { if ((rc = grow(&h->par_d, 0, (size_t)std::max(n, h->parcap * 2), h->stream))) return rc; h->parcap = std::max(n, h->parcap * 2); }
+    hipLaunchKernelGGL(k_unproc_emit, dim3(nb), dim3(PB), 0, h->stream, h->P, nv, h->bsum, from_end ? t.a - n : 0, n, h->idx_d, h->val_d,
+                       h->fl_d, h->par_d);
     HIP_TRY(hipGetLastError());
     std::vector<unsigned char> fl(n);
+    if (parent) HIP_TRY(hipMemcpyAsync(parent, h->par_d, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(idx, h->idx_d, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (val) HIP_TRY(hipMemcpyAsync(val, h->val_d, (size_t)n * h->d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(fl.data(), h->fl_d, n, hipMemcpyDeviceToHost, h->stream));

@@ -109,6 +109,7 @@ int  bslv_poly_add_cuts(bslv_poly *h, int B, const double *val /* B*dim */, cons
 int  bslv_poly_init(bslv_poly *h, int *rc_out);               /* poly__intl_apprx :153 */
 int  bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out); /* poly__get_vrtx :210 */
 int  bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count);
+int  bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
 int  bslv_poly_mark(bslv_poly *h, int n, const int *idx);     /* ST_BT(primal.sltn, idx) */
 int  bslv_poly_dual_adjacency(bslv_poly *h);                  /* poly__update_adjacence(&dual) :992 */
 /* batched incidence kernel on the current elements: hps = B x (dim+1) halfspaces (normal, alpha);
@@ -129,6 +130,32 @@ int  bslv_poly_get_dual(bslv_poly *h, unsigned char *used, unsigned char *ideal,
 int  bslv_poly_get_edges(bslv_poly *h, int *ab);
 int  bslv_poly_get_inc(bslv_poly *h, int *pairs);
 int  bslv_poly_get_dual_edges(bslv_poly *h, int *ab);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Batched Benson phase-2 driver  (replaces phase2_primal's loop, bslv_algs.c:958-1082,
+ *    and init_P2, :574-664).  Problem in the reference's normal form "min, c_q > 0"
+ *    (sol_init, bslv_vlp.c:845-861); A is m x n, P is q x n, dense row-major; bound types
+ *    'f','l','u','d','s' as in the .vlp format; R is q x r with generators as columns
+ *    (bslv_algs.c:599) -- R = Z = I for the default cone in the bounded case (-b, :943-956).
+ *    One outer iteration = collect -> solve_local -> (all-gather records) -> apply.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bslv_benson bslv_benson;
+
+int  bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, const double *P,
+                        const char *rtype, const double *rlb, const double *rub,
+                        const char *ctype, const double *clb, const double *cub,
+                        const double *R, int r, const double *c, double eps, int pool_slots);
+void bslv_benson_destroy(bslv_benson *h);
+int  bslv_benson_start(bslv_benson *h, int *vlp_status /* 0 ok, 1 infeasible, 2 unbounded */);
+int  bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int *n_local, int *n_total);
+int  bslv_benson_record_len(const bslv_benson *h);             /* q + 5 doubles */
+int  bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, int *lockstep_out);
+int  bslv_benson_apply(bslv_benson *h, int nrec, const double *records, long *stats /* 5, may be NULL */);
+int  bslv_benson_step(bslv_benson *h, int max_batch, long *stats /* 8 */, double *ms /* 3 */);
+int  bslv_benson_unprocessed_left(const bslv_benson *h);
+int  bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots);
+bslv_poly *bslv_benson_poly(bslv_benson *h);
+bslv_lpq  *bslv_benson_lp(bslv_benson *h);
 
 #ifdef __cplusplus
 }
