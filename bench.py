@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- scalar LPs/s (+ vertices enumerated/s) of the batched Benson hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched under
+torch.distributed.run, one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+
+  step      = one outer iteration of the re-shaped phase2_primal loop: collect the newest B*N
+              unprocessed vertices -> B LPs per GPU (batched dual simplex on HBM-resident tableaux)
+              -> one all_gather of the cut records -> every rank applies the cuts (GPU double
+              description).  Weak scaling: B LPs per GPU per step.
+  workload  = S-mid: synthetic VLP q=5, n=500, m=1000 (BASELINE.json configs[2]/[3]).
+  setup (untimed): problem generation, upload, cold start + the r weighted-sum LPs, and the ramp
+              of the vertex queue up to one full batch -- so every timed step has full batches and
+              all inputs (constraint matrix, tableau pool, polyhedron) are resident in HBM.
+  roofline  = the tableau-update kernel (k_update): algorithmic bytes = pivots * 16*(m+r+1)*(n+2)
+              (one read + one write of the eliminated tableau) / its HIP-event time,
+              measured live inside the timed region on the engine's stream.
+  cpu_baseline = the CPU oracle (oracle/benson_cpu.c: sequential loop, warm-started dense dual
+              simplex, 1 core) on the first LPs of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="S-mid")
+    ap.add_argument("--batch", type=int, default=0, help="LPs per GPU per step (default by workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bensolve_amd import synth
+    from bensolve_amd.benson import BensonEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    defaults = {"S-small": (2048, 20000), "S-mid": (1024, 120), "S-degenerate": (64, 4)}
+    B = args.batch or defaults.get(args.workload, (256, 50))[0]
+    cpu_lps = args.cpu_lps or defaults.get(args.workload, (256, 50))[1]
+    prob = synth.CONFIGS[args.workload]()
+    m, n, q = prob["m"], prob["n"], prob["q"]
+    r = q
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=4 * B + 64)
+    slot_bytes = eng.lp_call("slot_bytes")
+    st = eng.start()
+    if st != 0:
+        raise SystemExit("phase 2 start failed: vlp status %d" % st)
+
+    def one_step():
+        if world > 1:
+            return eng.step_distributed(B * world, dist, device)
+        nl, nt = eng.collect(B, 0, 1)
+        rec, piv, ls = eng.solve_local(nl)
+        s = eng.apply(rec)
+        s.update(n_local=nl, n_total=nt, pivots=piv, lockstep=ls)
+        return s
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ramp (untimed setup): grow the vertex queue to one full global batch
+    ramp_steps = 0
+    while True:
+        s = one_step()
+        ramp_steps += 1
+        left = eng.lib.bslv_benson_unprocessed_left(eng.h)
+        cnt = eng.poly_call("unprocessed", 0)[3]
+        if cnt >= B * world or ramp_steps > 200 or (s["n_total"] == 0):
+            break
+    for _ in range(args.warmup):
+        one_step()
+
+    eng.lp_call("set_profile", True)
+    nv0 = eng.poly_call("counts")["new_vertices"]
+    pt0 = eng.poly_call("counts")["pair_tests"]
+    lps = cuts = pivots = lockstep = 0
+    upd_ms = 0.0
+    lp_ms = 0.0
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s = one_step()
+        lps += s["lps"]
+        cuts += s["cuts"]
+        pivots += s["pivots"]
+        lockstep += s["lockstep"]
+        ls = eng.lp_call("last_stats")
+        upd_ms += ls["update_ms"]
+        lp_ms += ls["total_ms"]
+    sync()
+    dt = time.perf_counter() - t0
+    eng.lp_call("set_profile", False)
+    c1 = eng.poly_call("counts")
+    new_vertices = c1["new_vertices"] - nv0
+    pair_tests = c1["pair_tests"] - pt0
+    live = int(eng.poly_dump()["pu"].sum()) if c1["nprimal"] < 5_000_000 else -1
+
+    # max over ranks of the elapsed time; sums of the per-rank pivot counts
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        agg = torch.tensor([pivots, upd_ms], dtype=torch.float64, device=device)
+        allp = [torch.zeros_like(agg) for _ in range(world)]
+        dist.all_gather(allp, agg)
+        pivots_all = sum(float(a[0]) for a in allp)
+    else:
+        pivots_all = pivots
+
+    alg_bytes_per_pivot = 16.0 * (m + r + 1) * (n + 2)          # SURVEY 8d K3 / BASELINE.md 3.4
+    launches = max(lockstep, 1)
+    achieved = (pivots * alg_bytes_per_pivot) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_update (tableau rank-1 update)", "achieved": round(achieved, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "launches": launches, "avg_launch_us": round(upd_ms * 1e3 / launches, 2),
+                "alg_bytes_per_launch": round(pivots * alg_bytes_per_pivot / launches, 0),
+                "pivots_rank0": pivots}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api
+        t1 = time.perf_counter()
+        rc, fp, cst = oracle_api.benson_phase2_primal(prob, eps=1e-7, max_lps=cpu_lps)
+        fp.close()
+        cpu = {"value": round(cst.lps / cst.secs_total, 3), "unit": "LPs/s", "cores": 1, "kind": "port",
+               "sample": "oracle/benson_cpu.c (sequential phase2_primal loop, warm-started dense dual simplex + CPU double "
+                         "description; GLPK is not installed so the reference's LP half cannot run), first %d LPs of %s from "
+                         "a cold start, %.1f s, %d pivots; vertices/s %.1f" % (cst.lps, args.workload, cst.secs_total, cst.pivots,
+                                                                              cst.new_vertices / cst.secs_total),
+               "pivots_per_lp": round(cst.pivots / max(cst.lps, 1), 1)}
+
+    if rank == 0:
+        out = {
+            "metric": "scalar LPs/sec (Benson phase 2, batched P2(v) solves incl. cut application), synthetic VLP q=%d n=%d m=%d" % (q, n, m),
+            "value": round(lps / dt, 2), "unit": "LPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s (q=%d, n=%d, m=%d dense covering VLP, seed per SURVEY 8d)" % (args.workload, q, n, m),
+                       "lp_rows_cols": [m + q + r + 1, n + q + 1], "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "vertex batch sharded over %d GPU(s), one all_gather of cut records per step" % world,
+                       "tableau_slot_bytes": slot_bytes, "pool_slots": 4 * B + 64, "ramp_steps_untimed": ramp_steps},
+            "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts,
+            "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
+            "live_vertices": live, "lp_ms_rank0": round(lp_ms, 2), "update_kernel_ms_rank0": round(upd_ms, 2),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

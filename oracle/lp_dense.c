@@ -43,13 +43,16 @@ struct olp {
     double obj;
     int status;
     long iters, pivots;
+    unsigned char *art;   /* per variable: bit0 artificial lower bound -BIG, bit1 artificial upper bound +BIG */
 };
+#define ART_BIG 1e7
 
 static double lbv(const olp *lp, int k)
 {
     char t = k < lp->M ? lp->rtype[k] : lp->ctype[k - lp->M];
     double lb = k < lp->M ? lp->rlb[k] : lp->clb[k - lp->M];
-    return (t == 'l' || t == 'd' || t == 's') ? lb : -INFINITY;
+    if (t == 'l' || t == 'd' || t == 's') return lb;
+    return (lp->art && (lp->art[k] & 1)) ? -ART_BIG : -INFINITY;
 }
 static double ubv(const olp *lp, int k)
 {
@@ -57,7 +60,8 @@ static double ubv(const olp *lp, int k)
     double lb = k < lp->M ? lp->rlb[k] : lp->clb[k - lp->M];
     double ub = k < lp->M ? lp->rub[k] : lp->cub[k - lp->M];
     if (t == 's') return lb;
-    return (t == 'u' || t == 'd') ? ub : INFINITY;
+    if (t == 'u' || t == 'd') return ub;
+    return (lp->art && (lp->art[k] & 2)) ? ART_BIG : INFINITY;
 }
 static double cost(const olp *lp, int k) { return k < lp->M ? 0.0 : lp->c[k - lp->M + 1]; }
 
@@ -82,7 +86,7 @@ void olp_free(olp *lp)
     if (!lp) return;
     free_basis(lp);
     free(lp->A); free(lp->rtype); free(lp->ctype); free(lp->rlb); free(lp->rub);
-    free(lp->clb); free(lp->cub); free(lp->c);
+    free(lp->clb); free(lp->cub); free(lp->c); free(lp->art);
     free(lp);
 }
 
@@ -421,11 +425,47 @@ int olp_solve(olp *lp, int method)
     refresh_beta(lp);
     refresh_d(lp);
     int st;
-    if (method != OLP_PRIMAL && dual_feasible(lp)) {
+    if (method != OLP_PRIMAL && !dual_feasible(lp)) {
+        /* artificial-bounds start of the dual simplex: a nonbasic column whose reduced cost has the
+         * wrong sign for lack of a bound gets a temporary bound of +-1e7 on that side, which makes the
+         * basis dual feasible; if such a bound is still active at the end the LP is unbounded and
+         * the primal simplex below decides */
+        free(lp->art);
+        lp->art = (unsigned char *)calloc(lp->M + lp->N + 1, 1);
+        for (int j = 0; j < lp->N; j++) {
+            int k = lp->nh[j];
+            double dj = lp->d[j], lo = lbv(lp, k), up = ubv(lp, k);
+            if (lo == up) continue;
+            if (dj > TOL_DJ && isinf(lo)) lp->art[k] |= 1;
+            if (dj < -TOL_DJ && isinf(up)) lp->art[k] |= 2;
+        }
+        for (int j = 0; j < lp->N; j++) {
+            int k = lp->nh[j];
+            double dj = lp->d[j], lo = lbv(lp, k), up = ubv(lp, k);
+            if (lo == up || (isinf(lo) && isinf(up))) continue;
+            if (dj > TOL_DJ && !isinf(lo)) lp->nstat[j] = NS_L;
+            else if (dj < -TOL_DJ && !isinf(up)) lp->nstat[j] = NS_U;
+        }
+        sanitize(lp);
+        refresh_beta(lp);
+        if (dual_feasible(lp)) {
+            st = dual_simplex(lp);
+            int active = 0;
+            for (int j = 0; j < lp->N; j++) {
+                int k = lp->nh[j];
+                if (((lp->art[k] & 1) && lp->nstat[j] == NS_L) || ((lp->art[k] & 2) && lp->nstat[j] == NS_U)) active = 1;
+            }
+            free(lp->art); lp->art = NULL;
+            if (st == OLP_OPTIMAL && !active) goto done;
+            sanitize(lp); refresh_beta(lp); refresh_d(lp);
+        } else { free(lp->art); lp->art = NULL; sanitize(lp); refresh_beta(lp); }
+        st = primal_simplex(lp);
+    } else if (method != OLP_PRIMAL) {
         st = dual_simplex(lp);
         if (st == OLP_UNDEFINED) st = primal_simplex(lp);
     } else
         st = primal_simplex(lp);
+done:;
     /* objective from the structural values */
     double z = lp->c[0];
     for (int j = 0; j < lp->N; j++) z += lp->c[j + 1] * olp_col_prim(lp, j + 1);
