@@ -23,6 +23,7 @@ constexpr int MAXD = 16;
 constexpr double POLY_EPS = 1e-9;      // bslv_poly.h:47
 constexpr int PB = 256;                // threads per workgroup in the poly kernels
 constexpr unsigned char F_USED = 1, F_IDEAL = 2, F_SLTN = 4;
+constexpr int CRING = 1024;            // ring of per-cut classify counters
 
 struct Hp { double h[MAXD + 1]; };
 struct Tri { int a, b, c; };
@@ -68,7 +69,10 @@ __device__ Tri block_exscan(Tri v, Tri *tot, Tri *lds /* >= 16 */)
     return ex;
 }
 // scan of per-block sums by one workgroup; sums[] becomes exclusive prefixes, totals[0] the grand total
-__global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *totals)
+// host mailbox in mapped pinned memory: the scan tail publishes totals (and the classify counters)
+// straight to the host, which spins on `seq` instead of paying a stream synchronise per readback
+struct Mail { volatile int seq; int cnt[4]; Tri t; };
+__global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *totals, Mail *mail = nullptr, const int *counters = nullptr, int seq = 0)
 {
     __shared__ Tri lds[16];
     Tri carry{0, 0, 0};
@@ -81,7 +85,15 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *to
         carry = tri_add(carry, tot);
         __syncthreads();
     }
-    if (threadIdx.x == 0) totals[0] = carry;
+    if (threadIdx.x == 0) {
+        totals[0] = carry;
+        if (mail) {
+            mail->t = carry;
+            if (counters) for (int k = 0; k < 4; k++) mail->cnt[k] = counters[k];
+            __threadfence_system();
+            mail->seq = seq;
+        }
+    }
 }
 
 // ---------------- K1: classify ----------------
@@ -97,17 +109,22 @@ __device__ __forceinline__ signed char classify_one(const PolyView &P, const Hp 
 __global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters)
 {
     int i = blockIdx.x * PB + threadIdx.x;
-    int isminus = 0, iszero = 0;
+    int isminus = 0, iszero = 0, zlen = 0;
     if (i < nv) {
         unsigned char fl = P.flag[i];
         signed char c = 2;
         if (fl & F_USED) { c = classify_one(P, hp, i, fl); isminus = c < 0; iszero = c == 0; }
+        if (iszero) zlen = P.inc_len[i] + 1;       // upper bound of its rebuilt incidence list
         P.cls[i] = c;
     }
     unsigned long long bm = __ballot(isminus), bz = __ballot(iszero);
+    if (bz) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) zlen += __shfl_xor(zlen, o, WAVE);
+    }
     if ((threadIdx.x & 63) == 0) {
         if (bm) atomicAdd(&counters[0], __popcll(bm));
-        if (bz) atomicAdd(&counters[1], __popcll(bz));
+        if (bz) { atomicAdd(&counters[1], __popcll(bz)); atomicAdd(&counters[2], zlen); }
     }
 }
 
@@ -347,12 +364,30 @@ __global__ void k_iota_members(int *members, int nzero, int nv0, int ncross)
 // grid.x enumerates (row i, chunk of 256 columns j > i) in lexicographic order via rowblk[]:
 // block g handles row rowof[g], columns j0[g] .. j0[g]+255.
 struct PairBlk { int i, j0; };
+// closed form of the lexicographic (row i, 256-column chunk) enumeration over i < j < nm:
+// G(K) = sum_{k=1..K} ceil(k/256); blocks before row i: S(i) = G(nm-1) - G(nm-1-i)
+__host__ __device__ inline long long pair_G(long long K)
+{
+    long long f = K / PB;
+    return (long long)PB * f * (f + 1) / 2 + (K - PB * f) * (f + 1);
+}
+__device__ __forceinline__ PairBlk pair_block(int nm, long long g)
+{
+    const long long L = nm - 1, GL = pair_G(L);
+    int lo = 0, hi = nm - 2;                      // largest i with S(i) <= g
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (GL - pair_G(L - mid) <= g) lo = mid; else hi = mid - 1;
+    }
+    long long before = GL - pair_G(L - lo);
+    return PairBlk{lo, lo + 1 + (int)(g - before) * PB};
+}
 __global__ __launch_bounds__(PB) void k_pair_flags(PolyView P, const int *members, int nm, const PairBlk *blks,
                                                     unsigned char *pflag, Tri *bsum)
 {
     __shared__ Tri lds[16];
     __shared__ int s_row[1024];
-    const PairBlk pb = blks[blockIdx.x];
+    const PairBlk pb = blks ? blks[blockIdx.x] : pair_block(nm, blockIdx.x);
     const int vi = members[pb.i];
     const int ni = P.inc_len[vi];
     const int *Li = P.pool + P.inc_off[vi];
@@ -404,11 +439,86 @@ __global__ __launch_bounds__(PB) void k_pair_flags(PolyView P, const int *member
     (void)block_exscan(t, &tot, lds);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(PB) void k_pair_emit(const int *members, const PairBlk *blks, const unsigned char *pflag,
+
+// ---- K2 on a local incidence bit matrix -------------------------------------------------------
+// The members of the new facet only touch a few hundred facets.  Those get local ids (first-touch
+// atomics; any bijection gives the same result) and each member a bit column: bits[w*nm + m],
+// 64 local facets per word, transposed so that a wave reading word w of 64 consecutive members is
+// one coalesced 512-B load.  Pair prefilter = popcount of ANDed columns; superset sweep = ANDN.
+__global__ __launch_bounds__(PB) void k_local_ids(PolyView P, const int *members, int nm, int stamp, int *fstamp, int *flocal, int *nlocal)
+{
+    int m = blockIdx.x * PB + threadIdx.x;
+    if (m >= nm) return;
+    int v = members[m];
+    const int *L = P.pool + P.inc_off[v];
+    int n = P.inc_len[v];
+    for (int j = 0; j < n; j++) {
+        int g = L[j];
+        int old = atomicMax(&fstamp[g], stamp);
+        if (old < stamp) flocal[g] = atomicAdd(nlocal, 1);
+    }
+}
+__global__ __launch_bounds__(PB) void k_build_bits(PolyView P, const int *members, int nm, int W, const int *flocal, unsigned long long *bits)
+{
+    int m = blockIdx.x * PB + threadIdx.x;
+    if (m >= nm) return;
+    int v = members[m];
+    const int *L = P.pool + P.inc_off[v];
+    int n = P.inc_len[v];
+    for (int w = 0; w < W; w++) bits[(size_t)w * nm + m] = 0ull;
+    for (int j = 0; j < n; j++) {
+        int id = flocal[L[j]];
+        bits[(size_t)(id >> 6) * nm + m] |= 1ull << (id & 63);
+    }
+}
+__global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    extern __shared__ unsigned long long s_m[];      // W words of row i, then 4 x W words (one M per wave)
+    const PairBlk pb = pair_block(nm, blockIdx.x);
+    for (int w = threadIdx.x; w < W; w += PB) s_m[w] = bits[(size_t)w * nm + pb.i];
+    __syncthreads();
+    const int j = pb.j0 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long *Mw = s_m + W + (size_t)wave * W;
+    int nmut = 0;
+    if (j < nm)
+        for (int w = 0; w < W; w++) nmut += __popcll(s_m[w] & bits[(size_t)w * nm + j]);
+    bool cand = (j < nm) && ((d == 1) || (nmut >= d - 1));        // edge_test, bslv_poly.c:482-485
+    bool adj = cand;
+    unsigned long long todo = __ballot(cand && d > 1);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int cj = pb.j0 + (threadIdx.x - lane) + src;
+        // M = column i & column cj, shared by the wave through LDS
+        for (int w = lane; w < W; w += WAVE) Mw[w] = s_m[w] & bits[(size_t)w * nm + cj];
+        __builtin_amdgcn_wave_barrier();
+        bool found = false;
+        for (int base = 0; base < nm; base += WAVE) {
+            const int wv = base + lane;
+            bool hit = false;
+            if (wv < nm && wv != pb.i && wv != cj) {
+                hit = true;
+                for (int w = 0; w < W; w++)
+                    if (Mw[w] & ~bits[(size_t)w * nm + wv]) { hit = false; break; }
+            }
+            if (__ballot(hit)) { found = true; break; }           // some other element lies on all mutual facets
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == src) adj = !found;
+    }
+    Tri t{adj ? 1 : 0, 0, 0};
+    pflag[(size_t)blockIdx.x * PB + threadIdx.x] = adj ? 1 : 0;
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_pair_emit(const int *members, int nm, const PairBlk *blks, const unsigned char *pflag,
                                                    const Tri *bpre, int2 *E, int ebase)
 {
     __shared__ Tri lds[16];
-    const PairBlk pb = blks[blockIdx.x];
+    const PairBlk pb = blks ? blks[blockIdx.x] : pair_block(nm, blockIdx.x);
     unsigned char f = pflag[(size_t)blockIdx.x * PB + threadIdx.x];
     Tri t{f, 0, 0};
     Tri tot;
@@ -546,6 +656,11 @@ struct bslv_poly {
     Tri *totals = nullptr;            // device, 4 entries
     int *counters = nullptr;          // device, 4 ints
     Tri *totals_h = nullptr; int *counters_h = nullptr;   // pinned
+    Mail *mail_h = nullptr, *mail_d = nullptr;          // mapped pinned mailbox (3 entries)
+    int *fstamp = nullptr, *flocal = nullptr, *nlocal = nullptr; int fcap = 0;   // local facet ids of the cut in flight
+    unsigned long long *bits = nullptr; size_t bitscap = 0;                     // local incidence bit matrix
+    int mailseq = 0;
+    long cutseq = 0;
     PairBlk *blks = nullptr; int blkcap = 0;
     unsigned char *pflag = nullptr; size_t pflagcap = 0;
     // dual side (host)
@@ -678,7 +793,28 @@ static int new_dual(bslv_poly *h, const double *val, int ideal)
     return f;
 }
 
-// one cut on the device; *rc = 0 cut applied, 1 redundant
+// spin on the host mailbox (the scan tail writes it through mapped pinned memory); falls back to a
+// stream synchronise so that a device fault surfaces as an error instead of a hang
+static int wait_mail(bslv_poly *h, int slot, int seq)
+{
+    volatile Mail *m = h->mail_h + slot;
+    for (long spin = 0; m->seq != seq; spin++) {
+        if ((spin & 0xFFFF) == 0xFFFF) {
+            hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipSuccess) {
+                if (m->seq == seq) break;
+                set_error("poly engine: mailbox %d never reached seq %d", slot, seq);
+                return BSLV_E_STATE;
+            }
+            if (e != hipErrorNotReady) { set_error("poly engine: stream error %s", hipGetErrorString(e)); return BSLV_E_NODEVICE; }
+        }
+    }
+    __sync_synchronize();
+    return 0;
+}
+
+// one cut on the device; *rc = 0 cut applied, 1 redundant.  Two host round trips per cut:
+//   A: classify counters + edge totals   B: on-plane totals + adjacent-pair total
 static int do_cut(bslv_poly *h, int f, int *rc_out)
 {
     const int d = h->d, nv0 = h->nv;
@@ -687,67 +823,83 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
     memset(&hp, 0, sizeof(hp));
     memcpy(hp.h, &h->hp[(size_t)f * (d + 1)], (d + 1) * sizeof(double));
     int rc;
-    // K1
-    HIP_TRY(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), s));
-    const int nbv = (nv0 + PB - 1) / PB;
-    hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, h->counters);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->counters_h, h->counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const int nminus = h->counters_h[0], nzero = h->counters_h[1];
-    if (nminus == 0) { h->fapplied[f] = 0; *rc_out = 1; return 0; }
-    // E: flags + scan
-    const int ne0 = h->ne, nbe = (ne0 + PB - 1) / PB;
+    const int cslot = (int)(h->cutseq % CRING);
+    if (cslot == 0 && h->cutseq > 0) HIP_TRY(hipMemsetAsync(h->counters, 0, CRING * 4 * sizeof(int), s));
+    h->cutseq++;
+    int *counters = h->counters + 4 * cslot;
+    const int ne0 = h->ne, nbe = std::max(1, (ne0 + PB - 1) / PB), nbv = (nv0 + PB - 1) / PB;
     if ((rc = ensure_bsum(h, std::max(nbe, nbv) + 1))) return rc;
     const int2 *Eold = h->E[h->ecur];
     int2 *Enew = h->E[1 - h->ecur];
-    Tri te{0, 0, 0};
-    if (ne0 > 0) {
-        hipLaunchKernelGGL(k_edge_flags, dim3(nbe), dim3(PB), 0, s, h->P, Eold, ne0, h->eflag, h->bsum);
-        if ((rc = scan_totals(h, nbe, &te))) return rc;
-    }
+    // ---- round A: K1 + edge flags + scan -> host ----
+    hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters);
+    hipLaunchKernelGGL(k_edge_flags, dim3(nbe), dim3(PB), 0, s, h->P, Eold, ne0, h->eflag, h->bsum);
+    const int seqA = ++h->mailseq;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, nbe, h->totals + 0, h->mail_d + 0, counters, seqA);
+    HIP_TRY(hipGetLastError());
+    if ((rc = wait_mail(h, 0, seqA))) return rc;
+    const int nminus = h->mail_h[0].cnt[0], nzero = h->mail_h[0].cnt[1], zero_ub = h->mail_h[0].cnt[2];
+    const Tri te = h->mail_h[0].t;
+    if (nminus == 0) { h->fapplied[f] = 0; *rc_out = 1; return 0; }
     const int nsurv = te.a, ncross = te.b;
     if ((rc = ensure_vcap(h, nv0 + ncross))) return rc;
-    if ((rc = ensure_pool(h, (size_t)h->poolused + te.c))) return rc;
-    const unsigned pool_e = h->poolused;
-    if (ne0 > 0) {
-        hipLaunchKernelGGL(k_edge_emit, dim3(nbe), dim3(PB), 0, s, h->P, hp, f, Eold, ne0, h->eflag, h->bsum, h->totals, Enew,
-                           nv0, pool_e);
-        HIP_TRY(hipGetLastError());
-    }
-    h->poolused += te.c;
-    // Z: on-plane elements (+ clears used on MINUS)
-    Tri tz{0, 0, 0};
+    if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
+    const unsigned pool_e = h->poolused, pool_z = h->poolused + (unsigned)te.c;
+    // ---- round B: edge emit, on-plane rebuild, pair flags + scan -> host ----
+    hipLaunchKernelGGL(k_edge_emit, dim3(nbe), dim3(PB), 0, s, h->P, hp, f, Eold, ne0, h->eflag, h->bsum, h->totals + 0, Enew, nv0, pool_e);
     hipLaunchKernelGGL(k_vert_flags, dim3(nbv), dim3(PB), 0, s, h->P, nv0, h->bsum);
-    if ((rc = scan_totals(h, nbv, &tz))) return rc;
-    if (tz.a != nzero) { set_error("internal: ZERO count mismatch %d vs %d", tz.a, nzero); return BSLV_E_STATE; }
-    if ((rc = ensure_pool(h, (size_t)h->poolused + tz.c))) return rc;
-    hipLaunchKernelGGL(k_vert_emit, dim3(nbv), dim3(PB), 0, s, h->P, f, nv0, h->bsum, h->members, h->poolused);
-    h->poolused += tz.c;
+    const int seqB1 = ++h->mailseq;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, nbv, h->totals + 1, h->mail_d + 1, (const int *)nullptr, seqB1);
+    hipLaunchKernelGGL(k_vert_emit, dim3(nbv), dim3(PB), 0, s, h->P, f, nv0, h->bsum, h->members, pool_z);
     if (ncross > 0) hipLaunchKernelGGL(k_iota_members, dim3((ncross + 255) / 256), dim3(256), 0, s, h->members, nzero, nv0, ncross);
+    const int nm = nzero + ncross;
+    long long nbp = 0;
+    int seqB2 = 0;
+    if (nm >= 2) {
+        nbp = pair_G(nm - 1);
+        if (nbp > 0x7FFFFFF0ll) { set_error("new facet has too many elements (%d) for one pair launch", nm); return BSLV_E_CAPACITY; }
+        h->pair_tests += (long)nm * (nm - 1) / 2;
+        if ((size_t)nbp * PB > h->pflagcap) { size_t nc = std::max((size_t)nbp * PB, h->pflagcap * 2); if ((rc = grow(&h->pflag, 0, nc, s))) return rc; h->pflagcap = nc; }
+        if ((rc = ensure_bsum(h, (int)nbp + 1))) return rc;
+        // local incidence bit matrix: at most one local id per list entry of the members
+        const long long len_ub = (long long)te.c + zero_ub;
+        const int W = (int)((std::min<long long>(len_ub, h->nf) + 63) / 64);
+        if (h->nf > h->fcap) {
+            int nc = std::max(h->nf + 1024, h->fcap * 2);
+            if ((rc = grow(&h->fstamp, (size_t)h->fcap, (size_t)nc, s, true))) return rc;
+            if ((rc = grow(&h->flocal, 0, (size_t)nc, s))) return rc;
+            if (!h->nlocal && (rc = grow(&h->nlocal, 0, 4, s, true))) return rc;
+            h->fcap = nc;
+        }
+        if ((size_t)W * nm > h->bitscap) { size_t nc = std::max((size_t)W * nm, h->bitscap * 2); if ((rc = grow(&h->bits, 0, nc, s))) return rc; h->bitscap = nc; }
+        const size_t lds_bits = (size_t)W * 5 * sizeof(unsigned long long);
+        if (lds_bits <= 48 * 1024) {
+            HIP_TRY(hipMemsetAsync(h->nlocal, 0, sizeof(int), s));
+            const int nbm = (nm + PB - 1) / PB;
+            hipLaunchKernelGGL(k_local_ids, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, (int)h->cutseq, h->fstamp, h->flocal, h->nlocal);
+            hipLaunchKernelGGL(k_build_bits, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, h->flocal, h->bits);
+            hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, d, h->bits, nm, W, h->pflag, h->bsum);
+        } else      // enormous local facet sets: sorted-list version
+            hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)nbp), dim3(PB), 0, s, h->P, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum);
+        seqB2 = ++h->mailseq;
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, (int)nbp, h->totals + 2, h->mail_d + 2, (const int *)nullptr, seqB2);
+    }
     HIP_TRY(hipGetLastError());
+    if ((rc = wait_mail(h, 1, seqB1))) return rc;
+    const Tri tz = h->mail_h[1].t;
+    if (tz.a != nzero) { set_error("internal: ZERO count mismatch %d vs %d", tz.a, nzero); return BSLV_E_STATE; }
+    h->poolused += (unsigned)te.c + (unsigned)tz.c;
     h->nv = nv0 + ncross;
     h->ne = nsurv + ncross;
     h->ecur = 1 - h->ecur;
     h->new_vertices += ncross;
-    // K2: pairs of members
-    const int nm = nzero + ncross;
     if (nm >= 2) {
-        std::vector<PairBlk> blks;
-        for (int i = 0; i + 1 < nm; i++)
-            for (int j0 = i + 1; j0 < nm; j0 += PB) blks.push_back(PairBlk{i, j0});
-        const int nbp = (int)blks.size();
-        h->pair_tests += (long)nm * (nm - 1) / 2;
-        if (nbp > h->blkcap) { if ((rc = grow(&h->blks, 0, (size_t)std::max(nbp, h->blkcap * 2), s))) return rc; h->blkcap = std::max(nbp, h->blkcap * 2); }
-        if ((size_t)nbp * PB > h->pflagcap) { size_t nc = std::max((size_t)nbp * PB, h->pflagcap * 2); if ((rc = grow(&h->pflag, 0, nc, s))) return rc; h->pflagcap = nc; }
-        if ((rc = ensure_bsum(h, nbp + 1))) return rc;
-        HIP_TRY(hipMemcpyAsync(h->blks, blks.data(), (size_t)nbp * sizeof(PairBlk), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_pair_flags, dim3(nbp), dim3(PB), 0, s, h->P, h->members, nm, h->blks, h->pflag, h->bsum);
-        Tri tp{0, 0, 0};
-        if ((rc = scan_totals(h, nbp, &tp))) return rc;
+        if ((rc = wait_mail(h, 2, seqB2))) return rc;
+        const Tri tp = h->mail_h[2].t;
         if (tp.a > 0) {
             if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
-            hipLaunchKernelGGL(k_pair_emit, dim3(nbp), dim3(PB), 0, s, h->members, h->blks, h->pflag, h->bsum, h->E[h->ecur], h->ne);
+            hipLaunchKernelGGL(k_pair_emit, dim3((unsigned)nbp), dim3(PB), 0, s, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum,
+                               h->E[h->ecur], h->ne);
             HIP_TRY(hipGetLastError());
             h->ne += tp.a;
         }
@@ -828,8 +980,11 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     h->P.d = dim;
     auto fail = [&](int code) { bslv_poly_destroy(h); return code; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
-    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, 4 * sizeof(int)) != hipSuccess ||
-        hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess) {
+    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * 4 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc(&h->mail_h, 4 * sizeof(Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&h->mail_d, h->mail_h, 0) != hipSuccess ||
+        hipMemset(h->counters, 0, CRING * 4 * sizeof(int)) != hipSuccess) {
         set_error("allocation of scan scratch failed");
         return fail(BSLV_E_NOMEM);
     }
@@ -847,9 +1002,10 @@ void bslv_poly_destroy(bslv_poly *h)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters);
-    fr(h->blks); fr(h->pflag); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
+    fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->totals_h) (void)hipHostFree(h->totals_h);
     if (h->counters_h) (void)hipHostFree(h->counters_h);
+    if (h->mail_h) (void)hipHostFree((void *)h->mail_h);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1251,7 +1407,7 @@ int bslv_poly_dual_adjacency(bslv_poly *h)
         if (tp.a > 0) {
             if (out_d) { (void)hipFree(out_d); out_d = nullptr; }
             TRYC(hipMalloc(&out_d, (size_t)tp.a * sizeof(int2)));
-            hipLaunchKernelGGL(k_pair_emit, dim3(nbp), dim3(PB), 0, s, ids_d, h->blks, h->pflag, h->bsum, out_d, 0);
+            hipLaunchKernelGGL(k_pair_emit, dim3(nbp), dim3(PB), 0, s, ids_d, nm, h->blks, h->pflag, h->bsum, out_d, 0);
             size_t base = h->dual_edges.size();
             h->dual_edges.resize(base + 2 * (size_t)tp.a);
             TRYC(hipMemcpyAsync(&h->dual_edges[base], out_d, (size_t)tp.a * sizeof(int2), hipMemcpyDeviceToHost, s));
