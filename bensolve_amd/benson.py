@@ -145,23 +145,39 @@ class BensonEngine:
     def step_distributed(self, max_batch, dist, device):
         """one outer iteration over all ranks of `dist` (torch.distributed): the batch is dealt to
         ranks, each solves its shard, ONE all_gather of the padded record blocks, all apply."""
-        import torch
         rank, world = dist.get_rank(), dist.get_world_size()
         n_local, n_total = self.collect(max_batch, rank, world)
         rec, piv, ls = self.solve_local(n_local)
-        cap = (n_total + world - 1) // world + max(1, n_total // (4 * world)) + 1
-        block = torch.zeros((cap + 1, self.rec_len), dtype=torch.float64)
-        block[0, 0] = n_local
-        if n_local:
-            block[1:1 + n_local] = torch.from_numpy(rec)
-        block = block.to(device)
-        gathered = [torch.empty_like(block) for _ in range(world)]
-        dist.all_gather(gathered, block)
-        parts = []
-        for g in gathered:
-            g = g.cpu().numpy()
-            parts.append(g[1:1 + int(g[0, 0])])
-        allrec = np.concatenate(parts, axis=0) if parts else np.zeros((0, self.rec_len))
+        allrec = gather_records(dist, rec, n_total, self.rec_len, device)
         st = self.apply(allrec)
         st.update(n_local=n_local, n_total=n_total, pivots=piv, lockstep=ls)
         return st
+
+
+def shard_capacity(n_total, world):
+    """upper bound of one rank's shard (the dealing rule of bslv_benson_collect)"""
+    return (n_total + world - 1) // world + max(1, n_total // (4 * world)) + 1
+
+
+def gather_records(dist, rec, n_total, rec_len, device):
+    """The ONE collective of an outer iteration: every rank contributes a fixed-size
+    block [count ; records ; zero padding] and receives everybody's.  Returns the concatenated
+    records of all ranks (rank order; apply() sorts by source slot)."""
+    import torch
+    world = dist.get_world_size()
+    rec = np.asarray(rec, np.float64).reshape(-1, rec_len)
+    n_local = len(rec)
+    cap = shard_capacity(n_total, world)
+    assert n_local <= cap, "shard larger than the dealing rule allows"
+    block = torch.zeros((cap + 1, rec_len), dtype=torch.float64)
+    block[0, 0] = n_local
+    if n_local:
+        block[1:1 + n_local] = torch.from_numpy(rec)
+    block = block.to(device)
+    gathered = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(gathered, block)
+    parts = []
+    for g in gathered:
+        g = g.cpu().numpy()
+        parts.append(g[1:1 + int(g[0, 0])])
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, rec_len))

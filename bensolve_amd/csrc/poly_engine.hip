@@ -445,30 +445,37 @@ __global__ __launch_bounds__(PB) void k_pair_flags(PolyView P, const int *member
 // atomics; any bijection gives the same result) and each member a bit column: bits[w*nm + m],
 // 64 local facets per word, transposed so that a wave reading word w of 64 consecutive members is
 // one coalesced 512-B load.  Pair prefilter = popcount of ANDed columns; superset sweep = ANDN.
-__global__ __launch_bounds__(PB) void k_local_ids(PolyView P, const int *members, int nm, int stamp, int *fstamp, int *flocal, int *nlocal)
+// 8 lanes per member: list entries and bit words are spread over the lanes, so the dependent
+// global accesses of one member overlap instead of forming one serial chain
+constexpr int LPM = 8;
+__global__ __launch_bounds__(PB) void k_local_ids(PolyView P, const int *members, int nm, int W, int stamp, int *fstamp, int *flocal,
+                                                   int *nlocal, unsigned long long *bits)
 {
-    int m = blockIdx.x * PB + threadIdx.x;
+    int t = blockIdx.x * PB + threadIdx.x;
+    int m = t / LPM, sub = t % LPM;
     if (m >= nm) return;
+    for (int w = sub; w < W; w += LPM) bits[(size_t)w * nm + m] = 0ull;
     int v = members[m];
     const int *L = P.pool + P.inc_off[v];
     int n = P.inc_len[v];
-    for (int j = 0; j < n; j++) {
+    for (int j = sub; j < n; j += LPM) {
         int g = L[j];
+        if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= stamp) continue;
         int old = atomicMax(&fstamp[g], stamp);
         if (old < stamp) flocal[g] = atomicAdd(nlocal, 1);
     }
 }
 __global__ __launch_bounds__(PB) void k_build_bits(PolyView P, const int *members, int nm, int W, const int *flocal, unsigned long long *bits)
 {
-    int m = blockIdx.x * PB + threadIdx.x;
+    int t = blockIdx.x * PB + threadIdx.x;
+    int m = t / LPM, sub = t % LPM;
     if (m >= nm) return;
     int v = members[m];
     const int *L = P.pool + P.inc_off[v];
     int n = P.inc_len[v];
-    for (int w = 0; w < W; w++) bits[(size_t)w * nm + m] = 0ull;
-    for (int j = 0; j < n; j++) {
+    for (int j = sub; j < n; j += LPM) {
         int id = flocal[L[j]];
-        bits[(size_t)(id >> 6) * nm + m] |= 1ull << (id & 63);
+        atomicOr(&bits[(size_t)(id >> 6) * nm + m], 1ull << (id & 63));
     }
 }
 __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum)
@@ -875,8 +882,8 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
         const size_t lds_bits = (size_t)W * 5 * sizeof(unsigned long long);
         if (lds_bits <= 48 * 1024) {
             HIP_TRY(hipMemsetAsync(h->nlocal, 0, sizeof(int), s));
-            const int nbm = (nm + PB - 1) / PB;
-            hipLaunchKernelGGL(k_local_ids, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, (int)h->cutseq, h->fstamp, h->flocal, h->nlocal);
+            const int nbm = (nm * LPM + PB - 1) / PB;
+            hipLaunchKernelGGL(k_local_ids, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, (int)h->cutseq, h->fstamp, h->flocal, h->nlocal, h->bits);
             hipLaunchKernelGGL(k_build_bits, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, h->flocal, h->bits);
             hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, d, h->bits, nm, W, h->pflag, h->bsum);
         } else      // enormous local facet sets: sorted-list version

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures.  Runs ONLY in the build container (needs /root/reference
+compiled into oracle/_ref by `make -C oracle ref`, and scipy).  Fixtures are DATA: inputs and
+expected outputs, no reference text.
+
+  poly_ref.npz   canonicalised results of the REFERENCE polyhedron engine (bslv_poly.c, unmodified,
+                 via oracle/_ref/libref_poly.so) for fixed cut sequences
+  lp_highs.json  optimal objective values of P2(v) instances from scipy/HiGHS (independent solver;
+                 the reference's own LP solver, GLPK, is not installed: parity unpinned by the reference)
+  hybrid_*.npz   outputs of oracle/_ref/bensolve_hybrid (reference driver + reference polyhedron
+                 engine + oracle LP) on the ex/*.vlp suite and on small synthetic problems
+"""
+import itertools
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import poly_harness as ph          # noqa: E402
+from bensolve_amd import synth     # noqa: E402
+from bensolve_amd.lp import P2Model  # noqa: E402
+
+
+def poly_cases():
+    """name -> (dim, v2h, c, apex, vals, ideals, init_after)"""
+    cases = {}
+    for q, N, seed in [(2, 25, 9), (3, 300, 1), (4, 100, 3), (5, 120, 4), (6, 40, 6)]:
+        cases["tangent_q%d_N%d" % (q, N)] = (q, 0, None, False, ph.tangent_halfspaces(q, N, seed), None, q + 3)
+    for q in (3, 4, 5):
+        cube = np.vstack([np.eye(q), -np.eye(q)])
+        signs = np.array(list(itertools.product([-1, 1], repeat=q)), float)
+        cases["cube_q%d" % q] = (q, 0, None, False, cube, None, None)
+        cases["cube_trunc_q%d" % q] = (q, 0, None, False, np.vstack([cube, signs / (q - 2)]), None, None)
+        cases["cube_support_q%d" % q] = (q, 0, None, False, np.vstack([cube, signs / q]), None, None)
+        cases["cross_q%d" % q] = (q, 0, None, False, signs, None, None)
+        cases["cross_trunc_q%d" % q] = (q, 0, None, False, np.vstack([signs, cube * 2.0]), None, None)
+    # ordering cones of the example suite, given by generators (k lines of ex05 / ex08): cone_vertenum's sequence
+    cases["cone_ex05"] = (3, 0, None, True, np.array([[2, 4, 0], [4, 0, 2], [2, 2, -1], [0, 2, 4.0]]).T[:0].reshape(0, 3), None, None)
+    gens = read_cone("/root/reference/ex/ex05.vlp")
+    cases["cone_ex05"] = (gens.shape[1], 0, None, True, gens, [1] * len(gens), None)
+    gens = read_cone("/root/reference/ex/ex08.vlp")
+    cases["cone_ex08"] = (gens.shape[1], 0, None, True, gens, [1] * len(gens), None)
+    return cases
+
+
+def read_cone(path):
+    """generators (rows) from the k lines of a .vlp file (bslv_vlp.c:459-487); j=0 lines set c and are skipped"""
+    q = ngen = None
+    ent = []
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "p":
+            q, ngen = int(t[6]), int(t[9])
+        elif t[0] == "k" and int(t[2]) > 0:
+            ent.append((int(t[1]), int(t[2]), float(t[3])))
+    G = np.zeros((ngen, q))
+    for i, j, v in ent:
+        G[j - 1, i - 1] = v
+    return G
+
+
+def run_case(kind, case):
+    q, v2h, c, apex, vals, ideals, init_after = case
+    P = ph.FlatPoly(kind, q, v2h, c)
+    if apex:
+        P.dual0_apex()
+    rcs = ph.run_sequence(P, vals, ideals, init_after)
+    P.dual_adjacency()
+    can = ph.canonical(P.dump())
+    P.close()
+    return rcs, can
+
+
+def pack(can):
+    return dict(X=can["X"], pi=can["pi"], Y=can["Y"], di=can["di"],
+                E=np.array(sorted(can["E"]), np.int64).reshape(-1, 2), I=np.array(sorted(can["I"]), np.int64).reshape(-1, 2),
+                DE=np.array(sorted(can["DE"]), np.int64).reshape(-1, 2))
+
+
+def make_poly():
+    out = {}
+    for name, case in poly_cases().items():
+        rcs, can = run_case("ref", case)
+        q, v2h, c, apex, vals, ideals, init_after = case
+        out[name + "/in_vals"] = np.asarray(vals, float)
+        out[name + "/in_ideals"] = np.asarray([0] * len(vals) if ideals is None else ideals)
+        out[name + "/in_meta"] = np.array([q, v2h, int(apex), -1 if init_after is None else init_after])
+        out[name + "/rc"] = np.asarray(rcs)
+        for k, v in pack(can).items():
+            out[name + "/" + k] = v
+        print("poly", name, "primal", len(can["X"]), "dual", len(can["Y"]))
+    np.savez_compressed(os.path.join(HERE, "poly_ref.npz"), **out)
+
+
+def make_lp():
+    from scipy.optimize import linprog
+    rec = []
+    for (m, n, q, seed, B) in [(12, 6, 2, 3, 6), (30, 15, 3, 5, 8), (60, 30, 3, 7, 8), (40, 20, 4, 9, 8)]:
+        prob = synth.covering_vlp(m, n, q, seed)
+        model = P2Model(prob)
+        rng = np.random.default_rng(seed)
+        X = rng.random((B, n)) * (3.0 / n) + 1.0 / n
+        V = (X @ prob["P"].T) * rng.uniform(0.2, 1.2, size=(B, 1))
+        for v in V:
+            # min z  s.t. A x >= 1, x >= 0, P x - z <= v
+            c = np.zeros(n + 1); c[n] = 1
+            Aub = np.vstack([np.hstack([-prob["A"], np.zeros((m, 1))]), np.hstack([prob["P"], -np.ones((q, 1))])])
+            bub = np.concatenate([-np.ones(m), v])
+            res = linprog(c, A_ub=Aub, b_ub=bub, bounds=[(0, None)] * n + [(None, None)], method="highs")
+            assert res.status == 0
+            rec.append(dict(m=m, n=n, q=q, seed=seed, v=list(map(float, v)), obj=float(res.fun)))
+    json.dump(rec, open(os.path.join(HERE, "lp_highs.json"), "w"), indent=0)
+    print("lp goldens", len(rec))
+
+
+def run_hybrid(vlp_path, args):
+    exe = os.path.join(ROOT, "oracle", "_ref", "bensolve_hybrid")
+    with tempfile.TemporaryDirectory() as td:
+        base = os.path.join(td, "out")
+        p = subprocess.run([exe, vlp_path, "-m", "0", "-o", base] + args, capture_output=True, text=True, timeout=600)
+        res = dict(rc=p.returncode, stdout=p.stdout[-300:])
+        for suf in ("img_p", "img_d", "adj_p", "inc_p"):
+            f = base + "_" + suf + ".sol"
+            if os.path.exists(f):
+                res[suf] = open(f).read()
+        return res
+
+
+def parse_img(txt):
+    a = np.array([[float(x) for x in l.split()] for l in txt.strip().splitlines()])
+    return a[:, 0].astype(int), a[:, 1:]
+
+
+def make_hybrid():
+    out = {}
+    status = {}
+    for ex in ("ex01", "ex02", "ex03", "ex04", "ex05", "ex06", "ex08", "ex11"):
+        r = run_hybrid("/root/reference/ex/%s.vlp" % ex, [])
+        status[ex] = dict(rc=r["rc"], msg=r["stdout"].strip().splitlines()[-1] if r["stdout"].strip() else "")
+        if "img_p" in r:
+            t, X = parse_img(r["img_p"]); out[ex + "/p_type"] = t; out[ex + "/p"] = X
+            t, Y = parse_img(r["img_d"]); out[ex + "/d_type"] = t; out[ex + "/d"] = Y
+        print("hybrid", ex, status[ex])
+    with tempfile.TemporaryDirectory() as td:
+        for name, prob in (("syn_30x15_q3_s5", synth.covering_vlp(30, 15, 3, 5)), ("syn_60x30_q3_s7", synth.covering_vlp(60, 30, 3, 7)),
+                           ("syn_40x20_q4_s9", synth.covering_vlp(40, 20, 4, 9))):
+            path = os.path.join(td, name + ".vlp")
+            synth.write_vlp(prob, path)
+            r = run_hybrid(path, ["-b"])
+            t, X = parse_img(r["img_p"]); out[name + "/p_type"] = t; out[name + "/p"] = X
+            t, Y = parse_img(r["img_d"]); out[name + "/d_type"] = t; out[name + "/d"] = Y
+            print("hybrid", name, X.shape, Y.shape)
+    np.savez_compressed(os.path.join(HERE, "hybrid.npz"), **out)
+    json.dump(status, open(os.path.join(HERE, "hybrid_status.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    make_poly()
+    make_lp()
+    make_hybrid()
