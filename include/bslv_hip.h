@@ -157,6 +157,17 @@ int  bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivot
 bslv_poly *bslv_benson_poly(bslv_benson *h);
 bslv_lpq  *bslv_benson_lp(bslv_benson *h);
 
+/* ------------------------------------------------------------------------------------------
+ * 5. Host side that stays C: the .vlp reader (vlp_init, bslv_vlp.c:275-588; kept file-format
+ *    contract) and the result-file writers (poly_output, bslv_algs.c:50-144; formats of
+ *    bslv_poly.c:341-414).  Struct bslv_vlp: bensolve_amd/csrc/host/bslv_host.h.
+ * ------------------------------------------------------------------------------------------ */
+struct bslv_vlp;
+int  bslv_vlp_read(const char *path, struct bslv_vlp **out, int *err_line);
+void bslv_vlp_free(struct bslv_vlp *v);
+const char *bslv_vlp_message(const struct bslv_vlp *v);
+int  bslv_sol_write(bslv_poly *poly, const char *base, const char *suffix, int optdir, long *counts /* 4, may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif
