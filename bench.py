@@ -97,6 +97,7 @@ def main():
         one_step()
 
     eng.lp_call("set_profile", True)
+    rounds0 = eng.poly_call("rounds_run")
     nv0 = eng.poly_call("counts")["new_vertices"]
     pt0 = eng.poly_call("counts")["pair_tests"]
     lps = cuts = pivots = lockstep = 0
@@ -168,7 +169,7 @@ def main():
                        "tableau_slot_bytes": slot_bytes, "pool_slots": 4 * B + 64, "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
-            "live_vertices": live, "lp_ms_rank0": round(lp_ms, 2), "update_kernel_ms_rank0": round(upd_ms, 2),
+            "live_vertices": live, "poly_rounds": eng.poly_call("rounds_run") - rounds0, "lp_ms_rank0": round(lp_ms, 2), "update_kernel_ms_rank0": round(upd_ms, 2),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

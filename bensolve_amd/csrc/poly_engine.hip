@@ -644,11 +644,17 @@ __global__ __launch_bounds__(PB) void k_dpair_flags(PolyView P, DualView D, int 
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
+#include "poly_rounds_kernels.inc"
+
 }  // namespace bslv
 
 using namespace bslv;
 
+struct RoundsBuf;
 struct bslv_poly {
+    RoundsBuf *rounds = nullptr;      // scratch of the multi-cut path
+    int batch_mode = 1;               // 0: one cut at a time, 1: rounds of independent cuts
+    long rounds_run = 0, conf_pairs = 0, conf_cuts = 0;
     int d = 0, v2h = 0;
     std::vector<double> c;
     hipStream_t stream = nullptr;
@@ -673,6 +679,9 @@ struct bslv_poly {
     // dual side (host)
     std::vector<double> Y, hp;        // nf x d, nf x (d+1)
     std::vector<unsigned char> fapplied, fideal;
+    // incidence lists hold RANKS (order of application), so appending the newest cut keeps them sorted even
+    // when cuts of a batch are applied out of index order; facet_of_rank maps back to dual slot ids
+    std::vector<int> facet_of_rank;
     int nf = 0;
     bool initialised = false;
     std::vector<int> queue;
@@ -848,16 +857,18 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
     const int nminus = h->mail_h[0].cnt[0], nzero = h->mail_h[0].cnt[1], zero_ub = h->mail_h[0].cnt[2];
     const Tri te = h->mail_h[0].t;
     if (nminus == 0) { h->fapplied[f] = 0; *rc_out = 1; return 0; }
+    const int rank = (int)h->facet_of_rank.size();
+    h->facet_of_rank.push_back(f);
     const int nsurv = te.a, ncross = te.b;
     if ((rc = ensure_vcap(h, nv0 + ncross))) return rc;
     if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
     const unsigned pool_e = h->poolused, pool_z = h->poolused + (unsigned)te.c;
     // ---- round B: edge emit, on-plane rebuild, pair flags + scan -> host ----
-    hipLaunchKernelGGL(k_edge_emit, dim3(nbe), dim3(PB), 0, s, h->P, hp, f, Eold, ne0, h->eflag, h->bsum, h->totals + 0, Enew, nv0, pool_e);
+    hipLaunchKernelGGL(k_edge_emit, dim3(nbe), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, h->eflag, h->bsum, h->totals + 0, Enew, nv0, pool_e);
     hipLaunchKernelGGL(k_vert_flags, dim3(nbv), dim3(PB), 0, s, h->P, nv0, h->bsum);
     const int seqB1 = ++h->mailseq;
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, nbv, h->totals + 1, h->mail_d + 1, (const int *)nullptr, seqB1);
-    hipLaunchKernelGGL(k_vert_emit, dim3(nbv), dim3(PB), 0, s, h->P, f, nv0, h->bsum, h->members, pool_z);
+    hipLaunchKernelGGL(k_vert_emit, dim3(nbv), dim3(PB), 0, s, h->P, rank, nv0, h->bsum, h->members, pool_z);
     if (ncross > 0) hipLaunchKernelGGL(k_iota_members, dim3((ncross + 255) / 256), dim3(256), 0, s, h->members, nzero, nv0, ncross);
     const int nm = nzero + ncross;
     long long nbp = 0;
@@ -870,9 +881,10 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
         if ((rc = ensure_bsum(h, (int)nbp + 1))) return rc;
         // local incidence bit matrix: at most one local id per list entry of the members
         const long long len_ub = (long long)te.c + zero_ub;
-        const int W = (int)((std::min<long long>(len_ub, h->nf) + 63) / 64);
-        if (h->nf > h->fcap) {
-            int nc = std::max(h->nf + 1024, h->fcap * 2);
+        const int nranks = (int)h->facet_of_rank.size();
+        const int W = (int)((std::min<long long>(len_ub, nranks) + 63) / 64);
+        if (nranks > h->fcap) {
+            int nc = std::max(nranks + 1024, h->fcap * 2);
             if ((rc = grow(&h->fstamp, (size_t)h->fcap, (size_t)nc, s, true))) return rc;
             if ((rc = grow(&h->flocal, 0, (size_t)nc, s))) return rc;
             if (!h->nlocal && (rc = grow(&h->nlocal, 0, 4, s, true))) return rc;
@@ -918,6 +930,8 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
     return 0;
 }
 
+#include "poly_rounds_host.inc"
+
 static int upload_initial(bslv_poly *h, const std::vector<double> &X /* (d+1) x d */, const std::vector<std::vector<int>> &inc)
 {
     const int d = h->d, n = d + 1;
@@ -946,6 +960,8 @@ static int upload_initial(bslv_poly *h, const std::vector<double> &X /* (d+1) x 
     HIP_TRY(hipMemcpy(h->E[h->ecur], E.data(), E.size() * sizeof(int2), hipMemcpyHostToDevice));
     h->ne = (int)E.size();
     h->nv = n;
+    h->facet_of_rank.resize(h->nf);
+    for (int f = 0; f < h->nf; f++) h->facet_of_rank[f] = f;
     return 0;
 }
 
@@ -995,6 +1011,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
         set_error("allocation of scan scratch failed");
         return fail(BSLV_E_NOMEM);
     }
+    h->rounds = new RoundsBuf();
     // dual slot 0: "facet at infinity", ideal point (0,..,0,-1)  (bslv_poly.c:83-92)
     std::vector<double> z(dim, 0.0);
     z[dim - 1] = -1.0;
@@ -1010,6 +1027,7 @@ void bslv_poly_destroy(bslv_poly *h)
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
+    if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
     if (h->counters_h) (void)hipHostFree(h->counters_h);
     if (h->mail_h) (void)hipHostFree((void *)h->mail_h);
@@ -1114,6 +1132,7 @@ int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal,
     const int d = h->d;
     std::vector<int> fids(B);
     for (int b = 0; b < B; b++) fids[b] = new_dual(h, val + (size_t)b * d, ideal ? ideal[b] : 0);
+    if (h->batch_mode == 1 && B >= 2) return apply_cuts_rounds(h, fids, rc_out);
     std::vector<int> anym(B, 1);
     if (B >= 2) {
         int rc;
@@ -1222,6 +1241,7 @@ int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, do
     HIP_TRY(hipMemcpyAsync(fl.data(), h->fl_d, n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (ideal) for (int k = 0; k < n; k++) ideal[k] = (fl[k] & F_IDEAL) ? 1 : 0;
+    if (parent) for (int k = 0; k < n; k++) if (parent[k] >= 0) parent[k] = h->facet_of_rank[parent[k]];
     return 0;
 }
 
@@ -1257,6 +1277,14 @@ int bslv_poly_mark(bslv_poly *h, int n, const int *idx)
     return 0;
 }
 
+int bslv_poly_set_batch_mode(bslv_poly *h, int mode)
+{
+    if (!h || mode < 0 || mode > 1) return BSLV_E_ARG;
+    h->batch_mode = mode;
+    return 0;
+}
+long bslv_poly_rounds_run(const bslv_poly *h) { return h ? h->rounds_run : 0; }
+long bslv_poly_conflict_pairs(const bslv_poly *h) { return h ? h->conf_pairs : 0; }
 int bslv_poly_dim(const bslv_poly *h) { return h ? h->d : 0; }
 int bslv_poly_nprimal(const bslv_poly *h) { return h ? h->nv : 0; }
 int bslv_poly_ndual(const bslv_poly *h) { return h ? h->nf : 0; }
@@ -1320,7 +1348,7 @@ int bslv_poly_get_inc(bslv_poly *h, int *pairs)
     long n = 0;
     for (int i = 0; i < h->nv; i++) {
         if (!(fl[i] & F_USED)) continue;
-        for (int j = 0; j < len[i]; j++) { pairs[2 * n] = i; pairs[2 * n + 1] = pool[off[i] + j]; n++; }
+        for (int j = 0; j < len[i]; j++) { pairs[2 * n] = i; pairs[2 * n + 1] = h->facet_of_rank[pool[off[i] + j]]; n++; }
     }
     return 0;
 }
@@ -1344,7 +1372,7 @@ int bslv_poly_get_dual(bslv_poly *h, unsigned char *used, unsigned char *ideal, 
         if (rc) return rc;
         for (int i = 0; i < h->nv; i++) {
             if (!(fl[i] & F_USED)) continue;
-            for (int j = 0; j < len[i]; j++) { int f = pool[off[i] + j]; if (h->fapplied[f]) live[f] = 1; }
+            for (int j = 0; j < len[i]; j++) { int f = h->facet_of_rank[pool[off[i] + j]]; if (h->fapplied[f]) live[f] = 1; }
         }
     } else
         for (int f = 0; f < nf; f++) live[f] = h->fapplied[f];
@@ -1364,10 +1392,10 @@ int bslv_poly_dual_adjacency(bslv_poly *h)
     std::vector<unsigned char> fl; std::vector<unsigned> off; std::vector<int> len, pool;
     int rc = fetch_inc(h, fl, off, len, pool);
     if (rc) return rc;
-    const int nf = h->nf;
+    const int nf = (int)h->facet_of_rank.size();      // rank space (incidence lists hold ranks)
     std::vector<int> flen(nf, 0);
     std::vector<unsigned char> live(nf, 0);
-    for (int i = 0; i < h->nv; i++) if (fl[i] & F_USED) for (int j = 0; j < len[i]; j++) { int f = pool[off[i] + j]; flen[f]++; if (h->fapplied[f]) live[f] = 1; }
+    for (int i = 0; i < h->nv; i++) if (fl[i] & F_USED) for (int j = 0; j < len[i]; j++) { int f = pool[off[i] + j]; flen[f]++; if (h->fapplied[h->facet_of_rank[f]]) live[f] = 1; }
     std::vector<unsigned> foff(nf + 1, 0);
     for (int f = 0; f < nf; f++) foff[f + 1] = foff[f] + flen[f];
     std::vector<int> fpool(foff[nf] ? foff[nf] : 1), fill(nf, 0), ids;
@@ -1419,6 +1447,10 @@ int bslv_poly_dual_adjacency(bslv_poly *h)
             h->dual_edges.resize(base + 2 * (size_t)tp.a);
             TRYC(hipMemcpyAsync(&h->dual_edges[base], out_d, (size_t)tp.a * sizeof(int2), hipMemcpyDeviceToHost, s));
             TRYC(hipStreamSynchronize(s));
+            for (size_t k = base; k < h->dual_edges.size(); k += 2) {          // ranks -> dual slot ids
+                int a = h->facet_of_rank[h->dual_edges[k]], b = h->facet_of_rank[h->dual_edges[k + 1]];
+                h->dual_edges[k] = std::min(a, b); h->dual_edges[k + 1] = std::max(a, b);
+            }
         }
         row = r1;
     }

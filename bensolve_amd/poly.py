@@ -19,6 +19,9 @@ def _bind(lib):
     lib.bslv_poly_add.argtypes = [vp, vp, i, vp]
     lib.bslv_poly_add_cuts.argtypes = [vp, i, vp, vp, vp]
     lib.bslv_poly_init.argtypes = [vp, vp]
+    lib.bslv_poly_set_batch_mode.argtypes = [vp, i]
+    lib.bslv_poly_rounds_run.argtypes = [vp]
+    lib.bslv_poly_rounds_run.restype = ctypes.c_long
     lib.bslv_poly_next.argtypes = [vp, vp, vp, vp, vp]
     lib.bslv_poly_unprocessed.argtypes = [vp, i, vp, vp, vp, vp]
     lib.bslv_poly_mark.argtypes = [vp, i, vp]
@@ -78,6 +81,12 @@ class PolyEngine:
         idl = None if ideals is None else np.ascontiguousarray(ideals, np.int32)
         check(self.lib.bslv_poly_add_cuts(self.h, B, vals.ctypes.data, None if idl is None else idl.ctypes.data, rc.ctypes.data))
         return rc
+
+    def set_batch_mode(self, mode):
+        check(self.lib.bslv_poly_set_batch_mode(self.h, int(mode)))
+
+    def rounds_run(self):
+        return self.lib.bslv_poly_rounds_run(self.h)
 
     def init(self):
         rc = ctypes.c_int()

@@ -106,6 +106,10 @@ int  bslv_poly_dual0_apex(bslv_poly *h);                      /* cone_vertenum's
 int  bslv_poly_add(bslv_poly *h, const double *val, int ideal, int *rc_out);       /* poly__add_vrtx :104 */
 int  bslv_poly_add_cuts(bslv_poly *h, int B, const double *val /* B*dim */, const int *ideal /* may be NULL */,
                         int *rc_out /* B */);                 /* batched poly__add_vrtx */
+/* add_cuts strategy: 0 = one cut at a time (slot numbering identical to the sequential definition),
+ * 1 = rounds of independent cuts applied in one pass each (default; same sets, different slot numbers) */
+int  bslv_poly_set_batch_mode(bslv_poly *h, int mode);
+long bslv_poly_rounds_run(const bslv_poly *h);
 int  bslv_poly_init(bslv_poly *h, int *rc_out);               /* poly__intl_apprx :153 */
 int  bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out); /* poly__get_vrtx :210 */
 int  bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count);

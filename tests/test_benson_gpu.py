@@ -32,7 +32,7 @@ def test_phase2_sets_match_oracle(m, n, q, seed, batch):
     got = ph.canonical(eng.poly_dump(), decimals=6)
     tot = eng.totals()
     eng.close()
-    ph.assert_same(got, exp, rtol=1e-7, atol=1e-7)
+    ph.assert_benson_results_agree(got, exp)
     # every vertex needs at least one LP, every facet one
     assert tot["lps"] >= len(exp["X"]) - q
 
@@ -154,4 +154,4 @@ def test_two_ranks_match_single():
     eng.poly_call("dual_adjacency")
     single = ph.canonical(eng.poly_dump(), decimals=6)
     eng.close()
-    ph.assert_same(ph.canonical(dict(d0), decimals=6), single, rtol=1e-7, atol=1e-7)
+    ph.assert_benson_results_agree(ph.canonical(dict(d0), decimals=6), single)

@@ -13,9 +13,10 @@ from bensolve_amd.poly import PolyEngine
 pytestmark = pytest.mark.gpu
 
 
-def run_both(q, vals, ideals=None, init_after=None, apex=False, v2h=0, c=None, batched=False):
+def run_both(q, vals, ideals=None, init_after=None, apex=False, v2h=0, c=None, batched=False, mode=0):
     O = ph.FlatPoly("oracle", q, v2h, c)
     G = PolyEngine(q, v2h, c)
+    G.set_batch_mode(mode)
     if apex:
         O.dual0_apex(); G.dual0_apex()
     rco = ph.run_sequence(O, vals, ideals, init_after)
@@ -69,8 +70,49 @@ def test_batched_add_cuts_matches_sequential():
     D = ph.tangent_halfspaces(q, N, 12)
     # duplicates and far-away (redundant) halfspaces exercise the batched incidence prefilter
     D = np.vstack([D, D[:20], D[:20] * 0.5])
-    do, dg = run_both(q, D, init_after=q + 2, batched=True)
+    do, dg = run_both(q, D, init_after=q + 2, batched=True, mode=0)
     assert_slotwise_equal(do, dg)
+
+
+@pytest.mark.parametrize("q,N,seed,k0", [(3, 600, 31, 6), (4, 300, 32, 8), (5, 400, 33, 7), (6, 80, 34, 9)])
+def test_rounds_of_independent_cuts_match_sequential_sets(q, N, seed, k0):
+    """multi-cut path: independent cuts of a batch applied in one pass per round.  Slot numbers differ
+    from the sequential order; vertex / facet / incidence / adjacency sets and the redundancy verdicts
+    must not."""
+    D = ph.tangent_halfspaces(q, N, seed)
+    D = np.vstack([D, D[:15], D[5:25] * 0.5])
+    O = ph.FlatPoly("oracle", q)
+    rco = ph.run_sequence(O, D, init_after=k0)
+    G = PolyEngine(q)
+    G.set_batch_mode(1)
+    rcg = [G.add(D[i]) for i in range(k0)]
+    assert G.init() == 0
+    rcg += list(G.add_cuts(D[k0:]))
+    # the verdict "redundant" of an individual cut depends on the order among conflicting cuts (a far
+    # parallel copy applied before the near plane is cut away later instead of being rejected); the
+    # exact duplicates are rejected in any order, and the final sets below do not depend on the order
+    assert sum(rcg) >= 15 and sum(rcg) <= sum(rco)
+    assert G.rounds_run() < len(D) - k0          # cuts really were grouped
+    O.dual_adjacency(); G.dual_adjacency()
+    ph.assert_same(ph.canonical(O.dump()), ph.canonical(G.dump()), rtol=1e-12, atol=1e-12)
+    O.close(); G.close()
+
+
+@pytest.mark.parametrize("q", [3, 4, 5])
+def test_rounds_on_degenerate_inputs(q):
+    cube = np.vstack([np.eye(q), -np.eye(q)])
+    signs = np.array(list(itertools.product([-1, 1], repeat=q)), float)
+    for vals in (np.vstack([cube, signs / (q - 2)]), np.vstack([cube, signs / q]), np.vstack([signs, cube * 2.0])):
+        k0 = 2 * q + 2
+        O = ph.FlatPoly("oracle", q)
+        rco = ph.run_sequence(O, vals, init_after=k0)
+        G = PolyEngine(q)
+        rcg = [G.add(vals[i]) for i in range(k0)]
+        assert G.init() == 0
+        rcg += list(G.add_cuts(vals[k0:]))
+        O.dual_adjacency(); G.dual_adjacency()
+        ph.assert_same(ph.canonical(O.dump()), ph.canonical(G.dump()))
+        O.close(); G.close()
 
 
 def test_cone_with_ideal_generators():
@@ -144,6 +186,7 @@ def test_full_size_properties_q5_N1000():
         G.add(D[k])
     assert G.init() == 0
     rc = G.add_cuts(D[q + 3:])
+    assert G.rounds_run() < len(D) - q - 3     # some cuts were grouped
     d = G.dump()
     live = d["pu"].astype(bool)
     X = d["X"]
