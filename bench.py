@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--workload", default="S-mid")
     ap.add_argument("--batch", type=int, default=0, help="LPs per GPU per step (default by workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--policy", type=int, default=0, help="batch selection: 1 newest first, 2 spread (default by workload)")
     ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
     args = ap.parse_args()
 
@@ -65,6 +66,8 @@ def main():
     r = q
     eng = BensonEngine(prob, eps=1e-7, pool_slots=4 * B + 64)
     slot_bytes = eng.lp_call("slot_bytes")
+    if args.policy:
+        eng.set_policy(args.policy)
     st = eng.start()
     if st != 0:
         raise SystemExit("phase 2 start failed: vlp status %d" % st)

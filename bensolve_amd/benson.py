@@ -27,6 +27,7 @@ def _bind(lib):
     lib.bslv_benson_apply.argtypes = [vp, i, vp, vp]
     lib.bslv_benson_step.argtypes = [vp, i, vp, vp]
     lib.bslv_benson_unprocessed_left.argtypes = [vp]
+    lib.bslv_benson_set_policy.argtypes = [vp, i]
     lib.bslv_benson_totals.argtypes = [vp, vp, vp, vp]
     lib.bslv_benson_poly.argtypes = [vp]
     lib.bslv_benson_poly.restype = vp
@@ -95,6 +96,9 @@ class BensonEngine:
             self.close()
         except Exception:
             pass
+
+    def set_policy(self, policy):
+        check(self.lib.bslv_benson_set_policy(self.h, int(policy)))
 
     def start(self):
         st = ctypes.c_int()

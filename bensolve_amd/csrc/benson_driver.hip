@@ -42,6 +42,9 @@ struct bslv_benson {
     std::vector<int> l_pos, l_slot;                   // local shard: position in batch, dst slot
     int rank = 0, world = 1;
     int unprocessed_left = 0;
+    int policy = 1;                                   // 1: newest vertices first (depth first), 2: spread over the whole queue
+    std::vector<double> slot_src;                     // per slot: vertex its LP was solved for (pool_slots x q)
+    std::vector<char> slot_valid;
     // totals
     long tot_lps = 0, tot_cuts = 0, tot_pivots = 0;
 };
@@ -111,6 +114,8 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
     if (rc) { bslv_benson_destroy(h); return rc; }
     h->pool_slots = pool_slots;
     for (int s = pool_slots - 1; s >= 1; s--) h->free_slots.push_back(s);
+    h->slot_src.assign((size_t)pool_slots * q, 0.0);
+    h->slot_valid.assign(pool_slots, 0);
     *out = h;
     return 0;
 }
@@ -163,11 +168,11 @@ int bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int 
     h->rank = rank; h->world = world;
     int rc, cnt = 0;
     for (;;) {
-        if ((rc = bslv_poly_unprocessed2(h->poly, 0, 1, nullptr, nullptr, nullptr, nullptr, &cnt))) return rc;
+        if ((rc = bslv_poly_unprocessed2(h->poly, 0, h->policy, nullptr, nullptr, nullptr, nullptr, &cnt))) return rc;
         int nb = std::min(cnt, max_batch);
         std::vector<int> idx(nb), ideal(nb), parent(nb);
         std::vector<double> val((size_t)nb * q);
-        if (nb && (rc = bslv_poly_unprocessed2(h->poly, nb, 1, idx.data(), val.data(), ideal.data(), parent.data(), &cnt))) return rc;
+        if (nb && (rc = bslv_poly_unprocessed2(h->poly, nb, h->policy, idx.data(), val.data(), ideal.data(), parent.data(), &cnt))) return rc;
         std::vector<int> dirs;
         h->b_idx.clear(); h->b_val.clear(); h->b_parent.clear();
         for (int k = 0; k < nb; k++) {
@@ -232,10 +237,29 @@ int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, in
     std::vector<double> vlo((size_t)nl * r, -INFINITY), vup((size_t)nl * r);
     h->l_slot.assign(nl, -1);
     // sources first (eviction below must not take a slot we are about to read)
+    // warm-start source: the tableau of the LP whose cut created the vertex; if that was evicted, the
+    // resident tableau whose own vertex is nearest (every optimal tableau is dual feasible for every v)
+    std::vector<int> cand;
+    if (h->policy == 2) {
+        const int step = std::max(1, (int)h->parents.size() / 768);
+        int c = 0;
+        for (auto &pr : h->parents) if ((c++ % step) == 0 && pr.first >= 0 && h->slot_valid[pr.second]) cand.push_back(pr.second);
+    }
     for (int k = 0; k < nl; k++) {
         int f = h->b_parent[h->l_pos[k]];
         auto it = h->facet_slot.find(f);
         src[k] = (it != h->facet_slot.end()) ? it->second : 0;
+        if (it == h->facet_slot.end() && !cand.empty()) {
+            const double *v = &h->b_val[(size_t)h->l_pos[k] * q];
+            double best = INFINITY; int bs = 0;
+            for (int s : cand) {
+                const double *u = &h->slot_src[(size_t)s * q];
+                double dd = 0;
+                for (int kk = 0; kk < q; kk++) dd += (u[kk] - v[kk]) * (u[kk] - v[kk]);
+                if (dd < best) { best = dd; bs = s; }
+            }
+            src[k] = bs;
+        }
     }
     std::vector<char> is_src(h->pool_slots, 0);
     for (int k = 0; k < nl; k++) is_src[src[k]] = 1;
@@ -253,6 +277,8 @@ int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, in
         dst[k] = s;
         h->l_slot[k] = s;
         const double *v = &h->b_val[(size_t)h->l_pos[k] * q];
+        memcpy(&h->slot_src[(size_t)s * q], v, q * sizeof(double));
+        h->slot_valid[s] = 1;
         for (int j = 0; j < r; j++) {                   // rows->ub[j] = R_j . v   (bslv_algs.c:1041-1046)
             double ub = 0;
             for (int kk = 0; kk < q; kk++) ub += h->R[(size_t)kk * r + j] * v[kk];
@@ -363,6 +389,12 @@ int bslv_benson_step(bslv_benson *h, int max_batch, long *stats, double *ms)
 }
 
 int bslv_benson_unprocessed_left(const bslv_benson *h) { return h ? h->unprocessed_left : 0; }
+int bslv_benson_set_policy(bslv_benson *h, int policy)
+{
+    if (!h || policy < 1 || policy > 2) return BSLV_E_ARG;
+    h->policy = policy;
+    return 0;
+}
 int bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots)
 {
     if (!h) return BSLV_E_ARG;

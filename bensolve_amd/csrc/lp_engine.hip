@@ -347,31 +347,42 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int B)
     __syncthreads();
     const double2 *p2 = reinterpret_cast<const double2 *>(s_prow);
     const int q2 = d.q >> 1, qodd = d.q & 1;
-    for (int rr = wave; rr < TR; rr += NT / WAVE) {
-        int i = blockIdx.x * TR + rr;
-        if (i >= L.Mp1) break;
-        double2 *t2 = reinterpret_cast<double2 *>(T + (size_t)i * ld);
-        if (i == d.r) {
-            for (int j2 = lane; j2 < ld2; j2 += WAVE) {
-                double2 pr = p2[j2], v;
-                v.x = -pr.x * d.p;
-                v.y = -pr.y * d.p;
-                if (j2 == q2) { if (qodd) v.y = d.p; else v.x = d.p; }
-                t2[j2] = v;
-            }
-            if (lane == 0) beta[i] = d.enter_val;
-            continue;
-        }
-        const double f = T[(size_t)i * ld + d.q] * d.p;
-        if (f == 0.0) continue;           // row untouched by this pivot
+    // each wave owns TR/4 consecutive rows and streams them two at a time: the multipliers f of both rows
+    // are fetched first, then both rows' loads are in flight before the first store (more bytes in
+    // flight per CU than one row at a time)
+    constexpr int RPW = TR / (NT / WAVE);
+    const int row0 = blockIdx.x * TR + wave * RPW;
+    for (int rr = 0; rr < RPW; rr += 2) {
+        const int i0 = row0 + rr, i1 = i0 + 1;
+        if (i0 >= L.Mp1) break;
+        const bool has1 = i1 < L.Mp1;
+        double2 *t0 = reinterpret_cast<double2 *>(T + (size_t)i0 * ld);
+        double2 *t1 = reinterpret_cast<double2 *>(T + (size_t)(has1 ? i1 : i0) * ld);
+        const bool piv0 = (i0 == d.r), piv1 = has1 && (i1 == d.r);
+        const double f0 = piv0 ? 0.0 : T[(size_t)i0 * ld + d.q] * d.p;
+        const double f1 = (!has1 || piv1) ? 0.0 : T[(size_t)i1 * ld + d.q] * d.p;
+        const bool do0 = piv0 || f0 != 0.0, do1 = has1 && (piv1 || f1 != 0.0);     // f == 0: row untouched by this pivot
+        if (!do0 && !do1) continue;
         for (int j2 = lane; j2 < ld2; j2 += WAVE) {
-            double2 v = t2[j2], pr = p2[j2];
-            v.x = fma(-f, pr.x, v.x);
-            v.y = fma(-f, pr.y, v.y);
-            if (j2 == q2) { if (qodd) v.y = f; else v.x = f; }
-            t2[j2] = v;
+            const double2 pr = p2[j2];
+            double2 v0, v1;
+            if (do0 && !piv0) v0 = t0[j2];
+            if (do1 && !piv1) v1 = t1[j2];
+            if (do0) {
+                if (piv0) { v0.x = -pr.x * d.p; v0.y = -pr.y * d.p; if (j2 == q2) { if (qodd) v0.y = d.p; else v0.x = d.p; } }
+                else { v0.x = fma(-f0, pr.x, v0.x); v0.y = fma(-f0, pr.y, v0.y); if (j2 == q2) { if (qodd) v0.y = f0; else v0.x = f0; } }
+                t0[j2] = v0;
+            }
+            if (do1) {
+                if (piv1) { v1.x = -pr.x * d.p; v1.y = -pr.y * d.p; if (j2 == q2) { if (qodd) v1.y = d.p; else v1.x = d.p; } }
+                else { v1.x = fma(-f1, pr.x, v1.x); v1.y = fma(-f1, pr.y, v1.y); if (j2 == q2) { if (qodd) v1.y = f1; else v1.x = f1; } }
+                t1[j2] = v1;
+            }
         }
-        if (lane == 0) beta[i] = fma(-f, d.pbeta, beta[i]);
+        if (lane == 0) {
+            if (do0) beta[i0] = piv0 ? d.enter_val : fma(-f0, d.pbeta, beta[i0]);
+            if (do1) beta[i1] = piv1 ? d.enter_val : fma(-f1, d.pbeta, beta[i1]);
+        }
     }
 }
 

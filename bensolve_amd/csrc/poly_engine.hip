@@ -545,7 +545,7 @@ __global__ __launch_bounds__(PB) void k_unproc_flags(PolyView P, int nv, Tri *bs
     (void)block_exscan(t, &tot, lds);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(PB) void k_unproc_emit(PolyView P, int nv, const Tri *bpre, int skip, int maxout, int *idx, double *val,
+__global__ __launch_bounds__(PB) void k_unproc_emit(PolyView P, int nv, const Tri *bpre, int skip, int maxout, int total, int *idx, double *val,
                                                      unsigned char *fl_out, int *parent)
 {
     __shared__ Tri lds[16];
@@ -556,7 +556,12 @@ __global__ __launch_bounds__(PB) void k_unproc_emit(PolyView P, int nv, const Tr
     Tri tot;
     Tri ex = block_exscan(t, &tot, lds);
     if (i >= nv || !t.a) return;
-    int pos = bpre[blockIdx.x].a + ex.a - skip;
+    int pos = bpre[blockIdx.x].a + ex.a;
+    if (total > 0) {              // strided sample: maxout elements spread evenly over the `total` unprocessed ones
+        long long a = (long long)pos * maxout / total, b = (long long)(pos + 1) * maxout / total;
+        if (b == a) return;
+        pos = (int)a;
+    } else pos -= skip;
     if (pos < 0 || pos >= maxout) return;
     idx[pos] = i;
     fl_out[pos] = fl;
@@ -1207,7 +1212,8 @@ int bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int 
 {
     return bslv_poly_unprocessed2(h, max_out, 0, idx, val, ideal, nullptr, count);
 }
-// from_end != 0: the max_out NEWEST unprocessed elements (highest slots); parent[k] = newest facet
+// from_end == 1: the max_out NEWEST unprocessed elements (highest slots); == 2: max_out elements spread
+// evenly over all unprocessed ones (every total/max_out-th); parent[k] = newest facet
 // through element k (the cut that created it), -1 if none
 int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count)
 {
@@ -1231,8 +1237,8 @@ int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, do
         h->outcap = nc;
     }
     if (n > h->parcap) { if ((rc = grow(&h->par_d, 0, (size_t)std::max(n, h->parcap * 2), h->stream))) return rc; h->parcap = std::max(n, h->parcap * 2); }
-    hipLaunchKernelGGL(k_unproc_emit, dim3(nb), dim3(PB), 0, h->stream, h->P, nv, h->bsum, from_end ? t.a - n : 0, n, h->idx_d, h->val_d,
-                       h->fl_d, h->par_d);
+    hipLaunchKernelGGL(k_unproc_emit, dim3(nb), dim3(PB), 0, h->stream, h->P, nv, h->bsum, from_end == 1 ? t.a - n : 0, n, from_end == 2 ? t.a : 0,
+                       h->idx_d, h->val_d, h->fl_d, h->par_d);
     HIP_TRY(hipGetLastError());
     std::vector<unsigned char> fl(n);
     if (parent) HIP_TRY(hipMemcpyAsync(parent, h->par_d, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -157,6 +157,8 @@ int  bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, i
 int  bslv_benson_apply(bslv_benson *h, int nrec, const double *records, long *stats /* 5, may be NULL */);
 int  bslv_benson_step(bslv_benson *h, int max_batch, long *stats /* 8 */, double *ms /* 3 */);
 int  bslv_benson_unprocessed_left(const bslv_benson *h);
+/* batch selection: 1 = newest vertices first (default), 2 = spread evenly over the unprocessed queue */
+int  bslv_benson_set_policy(bslv_benson *h, int policy);
 int  bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots);
 bslv_poly *bslv_benson_poly(bslv_benson *h);
 bslv_lpq  *bslv_benson_lp(bslv_benson *h);
