@@ -130,40 +130,112 @@ __global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int 
 
 // Batched incidence kernel: classes of nv elements against B halfspaces, 2 bits
 // each (0 dead, 1 MINUS, 2 ZERO, 3 PLUS), 32 halfspaces per 64-bit word, out[w*cap + i];
-// anyminus[b] != 0 iff some live element violates halfspace b.  Algorithmic bytes:
+// anyminus[w] gets bit bb set iff some live element violates halfspace 32 w + bb.  Algorithmic bytes:
 // 8 d nv (coords) + nv (flags) + 8 (d+1) B (halfspaces) + nv B / 4 (classes).
-__global__ __launch_bounds__(PB) void k_classify_batch(PolyView P, const double *hps /* B x (d+1) */, int B, int nv,
-                                                       unsigned long long *out, int *anyminus)
+// hps holds (d+3) doubles per halfspace: normal, alpha, alpha+EPS, alpha-EPS (thresholds precomputed on the host:
+// the scalar unit has no fp64 add).  The halfspace coefficients are wave-uniform: they are read through scalar loads (no LDS, no VGPR
+// traffic) and enter the fp64 FMAs as scalar operands; coordinates stay in registers (D is a
+// template parameter).  `touch`/`first` (optional) = number of non-PLUS halfspaces per element and the
+// first of them, for the multi-cut path.
+// spread the 32 bits of x to the even bit positions of a 64-bit word
+__device__ __forceinline__ unsigned long long spread32(unsigned x)
 {
-    extern __shared__ double s_hp[];
-    const int d = P.d;
-    for (int t = threadIdx.x; t < B * (d + 1); t += PB) s_hp[t] = hps[t];
-    __syncthreads();
-    int i = blockIdx.x * PB + threadIdx.x;
+    unsigned long long v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+template <int D, bool TOUCH>
+__global__ __launch_bounds__(PB) void k_classify_batch_t(PolyView P, const double *__restrict__ hps, int B, int nv,
+                                                         unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
+                                                         int *__restrict__ tc, int *__restrict__ t1)
+{
+    const int d = D > 0 ? D : P.d;
+    const int i = blockIdx.x * PB + threadIdx.x;
     bool live = false, ideal = false;
-    double x[MAXD];
+    double x[D > 0 ? D : MAXD];
+#pragma unroll
+    for (int k = 0; k < (D > 0 ? D : MAXD); k++) x[k] = 0.0;
     if (i < nv) {
         unsigned char fl = P.flag[i];
         live = fl & F_USED; ideal = fl & F_IDEAL;
 #pragma unroll
-        for (int k = 0; k < MAXD; k++) x[k] = k < d ? P.X[(size_t)k * P.cap + i] : 0.0;
+        for (int k = 0; k < (D > 0 ? D : MAXD); k++) if (k < d) x[k] = P.X[(size_t)k * P.cap + i];
     }
+    const bool wave_has_ideal = __ballot(ideal) != 0ull;      // directions are rare: scalar thresholds on the fast path
     const int nw = (B + 31) / 32;
+    int touch = 0, first = -1;
     for (int w = 0; w < nw; w++) {
-        unsigned long long word = 0;
-        for (int bb = 0; bb < 32; bb++) {
-            int b = w * 32 + bb;
-            if (b >= B) break;
-            const double *h = s_hp + b * (d + 1);
-            double s = 0.0;
-            for (int k = 0; k < d; k++) s = fma(h[k], x[k], s);
-            double a = ideal ? 0.0 : h[d];
-            unsigned long long c = !live ? 0ull : (s > a + POLY_EPS ? 3ull : (s > a - POLY_EPS ? 2ull : 1ull));
-            word |= c << (2 * bb);
-            unsigned long long anym = __ballot(c == 1ull);
-            if (anym && (threadIdx.x & 63) == 0) anyminus[b] = 1;   // benign race: all write 1
+        const int bend = min(32, B - w * 32);
+        const unsigned valid = bend == 32 ? 0xFFFFFFFFu : ((1u << bend) - 1u);
+        unsigned plus = 0, notminus = 0;       // bit bb: s > a + EPS ; s > a - EPS
+        if (!wave_has_ideal && bend == 32) {
+            // full word, compile-time trip count: the scalar loads of several halfspaces are batched ahead
+#pragma unroll
+            for (int bb = 0; bb < 32; bb++) {
+                const double *h = hps + (size_t)(w * 32 + bb) * (d + 3);      // wave-uniform address -> scalar loads
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < (D > 0 ? D : MAXD); k++) if (k < d) s = fma(h[k], x[k], s);
+                const double hi = h[d + 1], lo = h[d + 2];                    // alpha +- EPS, precomputed on the host
+                plus |= (unsigned)(s > hi) << bb;
+                notminus |= (unsigned)(s > lo) << bb;
+            }
+        } else if (!wave_has_ideal) {
+            for (int bb = 0; bb < bend; bb++) {
+                const double *h = hps + (size_t)(w * 32 + bb) * (d + 3);
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < (D > 0 ? D : MAXD); k++) if (k < d) s = fma(h[k], x[k], s);
+                const double hi = h[d + 1], lo = h[d + 2];
+                plus |= (unsigned)(s > hi) << bb;
+                notminus |= (unsigned)(s > lo) << bb;
+            }
+        } else {
+            for (int bb = 0; bb < bend; bb++) {
+                const double *h = hps + (size_t)(w * 32 + bb) * (d + 3);
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < (D > 0 ? D : MAXD); k++) if (k < d) s = fma(h[k], x[k], s);
+                const double a = ideal ? 0.0 : h[d];
+                plus |= (unsigned)(s > a + POLY_EPS) << bb;
+                notminus |= (unsigned)(s > a - POLY_EPS) << bb;
+            }
         }
-        if (i < nv) out[(size_t)w * P.cap + i] = word;
+        // class = 1 MINUS (01), 2 ZERO (10), 3 PLUS (11): low bit = plus | !notminus, high bit = notminus
+        unsigned lowb = (plus | ~notminus) & valid, highb = notminus & valid;
+        unsigned minusbits = ~notminus & valid;
+        if (!live) { lowb = 0; highb = 0; minusbits = 0; }
+        if (i < nv) out[(size_t)w * P.cap + i] = spread32(lowb) | (spread32(highb) << 1);
+        if (TOUCH) {
+            const unsigned nonplus = live ? (~plus & valid) : 0u;
+            if (nonplus) { if (touch == 0) first = w * 32 + (__ffs((int)nonplus) - 1); touch += __popc(nonplus); }
+        }
+        if (anyminus) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) minusbits |= __shfl_xor(minusbits, o, WAVE);
+            // bits already published by another wave need no atomic (relaxed read; a stale value only costs an atomic)
+            if ((threadIdx.x & 63) == 0 && (minusbits & ~__hip_atomic_load(&anyminus[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+                atomicOr(&anyminus[w], minusbits);
+        }
+    }
+    if (TOUCH && i < nv) { tc[i] = touch; t1[i] = first; }
+}
+
+static void launch_classify_batch(hipStream_t s, PolyView P, const double *hps, int B, int nv, unsigned long long *out, unsigned *anyminus,
+                                  int *tc, int *t1)
+{
+    dim3 g((nv + PB - 1) / PB), b(PB);
+    switch (P.d) {
+#define CASE(D) case D: if (tc) hipLaunchKernelGGL((k_classify_batch_t<D, true>), g, b, 0, s, P, hps, B, nv, out, anyminus, tc, t1); \
+                       else hipLaunchKernelGGL((k_classify_batch_t<D, false>), g, b, 0, s, P, hps, B, nv, out, anyminus, tc, t1); break;
+        CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+    default: if (tc) hipLaunchKernelGGL((k_classify_batch_t<0, true>), g, b, 0, s, P, hps, B, nv, out, anyminus, tc, t1);
+             else hipLaunchKernelGGL((k_classify_batch_t<0, false>), g, b, 0, s, P, hps, B, nv, out, anyminus, tc, t1); break;
     }
 }
 
@@ -192,7 +264,7 @@ __device__ __forceinline__ int isect3_count(const int *a, int na, const int *b, 
 }
 
 // ---------------- E: edges ----------------
-// eflag: 0 dropped, 1 survives, 2 crossing with a MINUS (b PLUS), 3 crossing with b MINUS
+// eflag: 0 dropped, 1 survives, 4 survives and joins a ZERO to a PLUS element, 2 crossing with a MINUS (b PLUS), 3 crossing with b MINUS
 // per element triple: (survive, cross, new incidence-list length)
 __device__ __forceinline__ Tri edge_triple(const PolyView &P, const int2 e, unsigned char *fl)
 {
@@ -203,7 +275,7 @@ __device__ __forceinline__ Tri edge_triple(const PolyView &P, const int2 e, unsi
         f = (ca == -1) ? 2 : 3;
         t.b = 1;
         t.c = isect_count(P.pool + P.inc_off[e.x], P.inc_len[e.x], P.pool + P.inc_off[e.y], P.inc_len[e.y]) + 1;
-    } else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = 1; t.a = 1; }
+    } else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = (ca == 0 || cb == 0) ? 4 : 1; t.a = 1; }
     *fl = f;
     return t;
 }
@@ -229,7 +301,7 @@ __global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, 
     int2 ed{0, 0};
     if (e < ne) {
         f = eflag[e]; ed = E[e];
-        if (f == 1) t.a = 1;
+        if (f == 1 || f == 4) t.a = 1;
         else if (f >= 2) {
             t.b = 1;
             t.c = isect_count(P.pool + P.inc_off[ed.x], P.inc_len[ed.x], P.pool + P.inc_off[ed.y], P.inc_len[ed.y]) + 1;
@@ -240,7 +312,8 @@ __global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, 
     if (e >= ne) return;
     ex = tri_add(ex, bpre[blockIdx.x]);
     const int d = P.d;
-    if (f == 1) {
+    if (f == 1) Enew[ex.a] = ed;          // plain survivor: a streaming copy, no class lookups
+    else if (f == 4) {
         Enew[ex.a] = ed;
         // ZERO element keeps the facets it shares with a PLUS neighbour (bslv_poly.c:634-652)
         signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
@@ -258,7 +331,7 @@ __global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, 
                 j += (y <= x);
             }
         }
-    } else if (f >= 2) {
+    } else if (f == 2 || f == 3) {
         const int mi = (f == 2) ? ed.x : ed.y, pl = (f == 2) ? ed.y : ed.x;
         const int w = nv0 + ex.b;
         const bool im = P.flag[mi] & F_IDEAL, ip = P.flag[pl] & F_IDEAL;
@@ -649,6 +722,23 @@ __global__ __launch_bounds__(PB) void k_dpair_flags(PolyView P, DualView D, int 
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
+
+// measurement helper: overwrite the first nv element slots with synthetic live points (splitmix-like hash)
+__global__ void k_bench_fill(PolyView P, int nv, unsigned long long seed)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    for (int k = 0; k < P.d; k++) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)i * P.d + k + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        P.X[(size_t)k * P.cap + i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+    }
+    P.flag[i] = F_USED;
+    P.inc_len[i] = 0;
+    P.inc_off[i] = 0;
+}
 #include "poly_rounds_kernels.inc"
 
 }  // namespace bslv
@@ -694,9 +784,9 @@ struct bslv_poly {
     // stats
     long pair_tests = 0, new_vertices = 0, cuts_applied = 0;
     // scratch for batched classify
-    double *hps_d = nullptr; int hpscap = 0;
+    double *hps_d = nullptr; int hpscap = 0; std::vector<double> hps_stage;
     unsigned long long *clsw = nullptr; size_t clswcap = 0;
-    int *anyminus = nullptr; int anycap = 0;
+    unsigned *anyminus = nullptr; int anycap = 0;      // bit b%32 of word b/32: some element violates halfspace b
     int *idx_d = nullptr; double *val_d = nullptr; unsigned char *fl_d = nullptr; int outcap = 0;
     int *par_d = nullptr; int parcap = 0;
 };
@@ -800,6 +890,24 @@ static int scan_totals(bslv_poly *h, int nb, Tri *tot_out)
     HIP_TRY(hipMemcpyAsync(h->totals_h, h->totals, sizeof(Tri), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     *tot_out = h->totals_h[0];
+    return 0;
+}
+
+// upload B halfspaces (host layout (d+1): normal, alpha) in the kernel's layout (d+3): + alpha+EPS, alpha-EPS
+static int upload_hps(bslv_poly *h, const double *hp_host, int B)
+{
+    const int d = h->d;
+    int rc;
+    if (B > h->hpscap) { int nc = std::max(B, std::max(512, h->hpscap * 2)); if ((rc = grow(&h->hps_d, 0, (size_t)nc * (MAXD + 3), h->stream))) return rc; h->hpscap = nc; }
+    h->hps_stage.resize((size_t)B * (d + 3));
+    for (int b = 0; b < B; b++) {
+        const double *src = hp_host + (size_t)b * (d + 1);
+        double *dst = &h->hps_stage[(size_t)b * (d + 3)];
+        for (int k = 0; k <= d; k++) dst[k] = src[k];
+        dst[d + 1] = src[d] + POLY_EPS;
+        dst[d + 2] = src[d] - POLY_EPS;
+    }
+    HIP_TRY(hipMemcpyAsync(h->hps_d, h->hps_stage.data(), h->hps_stage.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return 0;
 }
 
@@ -1145,18 +1253,17 @@ int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal,
         const int chunkB = 512;        // halfspaces per launch: (d+1)*8*512 B of LDS
         for (int b0 = 0; b0 < B; b0 += chunkB) {
             int nb_ = std::min(chunkB, B - b0);
-            if (nb_ > h->hpscap) { if ((rc = grow(&h->hps_d, 0, (size_t)chunkB * (MAXD + 1), h->stream))) return rc; h->hpscap = chunkB; }
+            if ((rc = upload_hps(h, &h->hp[(size_t)fids[b0] * (d + 1)], nb_))) return rc;
             if (nb_ > h->anycap) { if ((rc = grow(&h->anyminus, 0, (size_t)chunkB, h->stream))) return rc; h->anycap = chunkB; }
             size_t need = (size_t)((nb_ + 31) / 32) * h->P.cap;
             if (need > h->clswcap) { if ((rc = grow(&h->clsw, 0, need, h->stream))) return rc; h->clswcap = need; }
-            HIP_TRY(hipMemcpyAsync(h->hps_d, &h->hp[(size_t)fids[b0] * (d + 1)], (size_t)nb_ * (d + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemsetAsync(h->anyminus, 0, nb_ * sizeof(int), h->stream));
-            hipLaunchKernelGGL(k_classify_batch, dim3((nv + PB - 1) / PB), dim3(PB), (size_t)nb_ * (d + 1) * sizeof(double), h->stream,
-                               h->P, h->hps_d, nb_, nv, h->clsw, h->anyminus);
+            HIP_TRY(hipMemsetAsync(h->anyminus, 0, ((nb_ + 31) / 32) * sizeof(unsigned), h->stream));
+            launch_classify_batch(h->stream, h->P, h->hps_d, nb_, nv, h->clsw, h->anyminus, nullptr, nullptr);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(&anym[b0], h->anyminus, nb_ * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            std::vector<unsigned> bits((nb_ + 31) / 32);
+            HIP_TRY(hipMemcpy(bits.data(), h->anyminus, bits.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+            for (int k = 0; k < nb_; k++) anym[b0 + k] = (bits[k >> 5] >> (k & 31)) & 1u;
         }
-        HIP_TRY(hipStreamSynchronize(h->stream));
     }
     for (int b = 0; b < B; b++) {
         if (!anym[b]) { h->fapplied[fids[b]] = 0; rc_out[b] = 1; continue; }
@@ -1173,23 +1280,21 @@ int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal,
 int bslv_poly_classify_batch(bslv_poly *h, int B, const double *hps, unsigned long long *words_out, int *anyminus_out, int repeats, float *ms_out)
 {
     if (!h || B < 1 || !hps || !h->initialised) { set_error("bslv_poly_classify_batch: bad argument"); return BSLV_E_ARG; }
-    const int d = h->d, nv = h->nv;
-    if ((size_t)B * (d + 1) * sizeof(double) > 60 * 1024) { set_error("classify_batch: B too large for LDS"); return BSLV_E_ARG; }
+    const int nv = h->nv;
+    if (B > 4096) { set_error("classify_batch: at most 4096 halfspaces per call"); return BSLV_E_ARG; }
     int rc;
-    if (B > h->hpscap) { if ((rc = grow(&h->hps_d, 0, (size_t)B * (MAXD + 1), h->stream))) return rc; h->hpscap = B; }
+    if ((rc = upload_hps(h, hps, B))) return rc;
     if (B > h->anycap) { if ((rc = grow(&h->anyminus, 0, (size_t)B, h->stream))) return rc; h->anycap = B; }
     size_t need = (size_t)((B + 31) / 32) * h->P.cap;
     if (need > h->clswcap) { if ((rc = grow(&h->clsw, 0, need, h->stream))) return rc; h->clswcap = need; }
-    HIP_TRY(hipMemcpyAsync(h->hps_d, hps, (size_t)B * (d + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemsetAsync(h->anyminus, 0, B * sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->anyminus, 0, ((B + 31) / 32) * sizeof(unsigned), h->stream));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     if (repeats < 1) repeats = 1;
     // one untimed launch, then `repeats` timed ones
     for (int it = 0; it <= repeats; it++) {
         if (it == 1) HIP_TRY(hipEventRecord(e0, h->stream));
-        hipLaunchKernelGGL(k_classify_batch, dim3((nv + PB - 1) / PB), dim3(PB), (size_t)B * (d + 1) * sizeof(double), h->stream,
-                           h->P, h->hps_d, B, nv, h->clsw, h->anyminus);
+        launch_classify_batch(h->stream, h->P, h->hps_d, B, nv, h->clsw, h->anyminus, nullptr, nullptr);
     }
     HIP_TRY(hipEventRecord(e1, h->stream));
     HIP_TRY(hipGetLastError());
@@ -1201,7 +1306,11 @@ int bslv_poly_classify_batch(bslv_poly *h, int B, const double *hps, unsigned lo
     if (words_out)
         for (int w = 0; w < (B + 31) / 32; w++)
             HIP_TRY(hipMemcpy(words_out + (size_t)w * nv, h->clsw + (size_t)w * h->P.cap, (size_t)nv * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (anyminus_out) HIP_TRY(hipMemcpy(anyminus_out, h->anyminus, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (anyminus_out) {
+        std::vector<unsigned> bits((B + 31) / 32);
+        HIP_TRY(hipMemcpy(bits.data(), h->anyminus, bits.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (int k = 0; k < B; k++) anyminus_out[k] = (bits[k >> 5] >> (k & 31)) & 1u;
+    }
     return 0;
 }
 
@@ -1291,6 +1400,21 @@ int bslv_poly_set_batch_mode(bslv_poly *h, int mode)
 }
 long bslv_poly_rounds_run(const bslv_poly *h) { return h ? h->rounds_run : 0; }
 long bslv_poly_conflict_pairs(const bslv_poly *h) { return h ? h->conf_pairs : 0; }
+// MEASUREMENT ONLY (bench / profiles): turns the engine into nv synthetic live points so that the
+// batched incidence kernel can be timed at sizes beyond the caches.  The polyhedron is destroyed.
+int bslv_poly_bench_fill(bslv_poly *h, int nv, unsigned long long seed)
+{
+    if (!h || nv < 1) return BSLV_E_ARG;
+    int rc;
+    if ((rc = ensure_vcap(h, nv))) return rc;
+    hipLaunchKernelGGL(k_bench_fill, dim3((nv + 255) / 256), dim3(256), 0, h->stream, h->P, nv, seed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->nv = nv; h->ne = 0; h->initialised = true;
+    if (h->facet_of_rank.empty()) h->facet_of_rank.push_back(0);
+    return 0;
+}
+
 int bslv_poly_dim(const bslv_poly *h) { return h ? h->d : 0; }
 int bslv_poly_nprimal(const bslv_poly *h) { return h ? h->nv : 0; }
 int bslv_poly_ndual(const bslv_poly *h) { return h ? h->nf : 0; }

@@ -27,6 +27,7 @@ def _bind(lib):
     lib.bslv_poly_mark.argtypes = [vp, i, vp]
     lib.bslv_poly_dual_adjacency.argtypes = [vp]
     lib.bslv_poly_classify_batch.argtypes = [vp, i, vp, vp, vp, i, vp]
+    lib.bslv_poly_bench_fill.argtypes = [vp, i, ctypes.c_ulonglong]
     for n in ("dim", "nprimal", "ndual"):
         getattr(lib, "bslv_poly_" + n).argtypes = [vp]
     for n in ("nedges", "ninc", "ndual_edges", "pair_tests", "new_vertices"):
@@ -127,6 +128,9 @@ class PolyEngine:
         check(self.lib.bslv_poly_classify_batch(self.h, B, hps.ctypes.data, None if words is None else words.ctypes.data,
                                                 anym.ctypes.data, repeats, ctypes.byref(ms)))
         return words, anym, ms.value
+
+    def bench_fill(self, nv, seed=1):
+        check(self.lib.bslv_poly_bench_fill(self.h, int(nv), int(seed)))
 
     def counts(self):
         L, h = self.lib, self.h

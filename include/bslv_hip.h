@@ -120,6 +120,8 @@ int  bslv_poly_dual_adjacency(bslv_poly *h);                  /* poly__update_ad
  * words_out: ceil(B/32) x nprimal 64-bit words, 2 bits per class (0 dead 1 MINUS 2 ZERO 3 PLUS) */
 int  bslv_poly_classify_batch(bslv_poly *h, int B, const double *hps, unsigned long long *words_out,
                               int *anyminus_out, int repeats, float *ms_out);
+/* MEASUREMENT ONLY: replace the polyhedron by nv synthetic live points (for timing the incidence kernel) */
+int  bslv_poly_bench_fill(bslv_poly *h, int nv, unsigned long long seed);
 /* counts and slot-indexed dumps (poly__vrtx2file / adj2file / inc2file write these, :341-414) */
 int  bslv_poly_dim(const bslv_poly *h);
 int  bslv_poly_nprimal(const bslv_poly *h);
