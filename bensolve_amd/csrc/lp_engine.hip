@@ -261,7 +261,11 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, int B)
             th = fmin(th, (fabs(drow[j]) + TOL_DJ) / fabs(a));
     }
     th = block_min(th, sv);
-    if (isinf(th)) {                      // no entering candidate: primal infeasible
+    if (isinf(th)) {                      // no entering candidate: primal infeasible ...
+        if (!Bv.verified[b]) {            // ... unless the violation is rounding debris in beta: recompute it first
+            if (tid == 0) Bv.mode[b] = MODE_REFRESH;
+            return;
+        }
         if (tid == 0) { Bv.status[b] = BSLV_LP_INFEASIBLE; Bv.mode[b] = MODE_NONE; }
         return;
     }

@@ -12,6 +12,24 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(bslv_[a-z0-9_]+)\s*\(", txt)))
 
 
+def compat_symbols():
+    txt = open(os.path.join(ROOT, "include", "bslv_lp_compat.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lp_[a-z_]+)\s*\(", txt)))
+
+
+def test_reference_lp_symbols_exported():
+    """the 17 lp_* symbols bslv_algs.o / bslv_main.o import from bslv_lp.c + lp_get_time"""
+    from bensolve_amd import load_library
+    lib = load_library()
+    syms = compat_symbols()
+    need = ["lp_init", "lp_update_extra_coeffs", "lp_set_mat_row", "lp_clear_obj_coeffs", "lp_set_obj_coeffs", "lp_set_rows",
+            "lp_set_rows_hom", "lp_set_cols", "lp_set_cols_hom", "lp_set_options", "lp_solve", "lp_obj_val",
+            "lp_primal_solution_cols", "lp_dual_solution_rows", "lp_dual_solution_cols", "lp_get_num", "lp_free"]
+    assert set(need) <= set(syms)
+    assert not [s for s in syms if not hasattr(lib, s)]
+
+
 def test_header_symbols_exported():
     from bensolve_amd import load_library
     lib = load_library()
