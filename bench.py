@@ -140,8 +140,15 @@ def main():
     alg_bytes_per_pivot = 16.0 * (m + r + 1) * (n + 2)          # SURVEY 8d K3 / BASELINE.md 3.4
     launches = max(lockstep, 1)
     achieved = (pivots * alg_bytes_per_pivot) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    # HBM traffic from the PMC counters: collected in separate rocprofv3 --pmc passes (profiles/r01_pmc_k_update.json,
+    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per pivot; scaled to this run's pivots per launch
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_k_update.json")
+    if args.workload == "S-mid" and os.path.exists(pmc_file):
+        per_pivot = json.load(open(pmc_file))["k_update"]["traffic_bytes_per_pivot"]
+        traffic = round(per_pivot * pivots / launches, 0)
     roofline = {"bound": "hbm", "kernel": "k_update (tableau rank-1 update)", "achieved": round(achieved, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "launches": launches, "avg_launch_us": round(upd_ms * 1e3 / launches, 2),
                 "alg_bytes_per_launch": round(pivots * alg_bytes_per_pivot / launches, 0),
                 "pivots_rank0": pivots}
