@@ -41,7 +41,7 @@ constexpr int NT = 256;       // threads per workgroup
 struct PivDesc { int r, q; double p, pbeta, enter_val; };
 
 struct LpView {
-    int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit;
+    int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit, bland_after;
     size_t slotT;
     double *T, *beta, *xN;
     int *bh, *nh, *nstat, *pos;
@@ -211,12 +211,15 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, int B)
     const int M = L.M, N = L.N, ld = L.ld;
 
     // Phase A: leaving row = largest bound violation; id = 2*i + (below ? 1 : 0)
+    // anti-cycling: after `bland_after` pivots (a healthy solve needs far fewer) switch to Bland's rule --
+    // smallest variable id among the infeasible rows, exact minimum ratio with smallest id among ties
+    const bool bland = Bv.iters[b] >= L.bland_after;
     ValIdx best{0.0, -1};
     for (int i = tid; i < M; i += NT) {
         int k = bh[i];
         double lo = LO(L, Bv, b, k), up = UP(L, Bv, b, k), bt = beta[i];
-        if (!isinf(lo)) { double v = lo - bt; if (v > btol(lo)) best = better_max(best, ValIdx{v, 2 * i + 1}); }
-        if (!isinf(up)) { double v = bt - up; if (v > btol(up)) best = better_max(best, ValIdx{v, 2 * i}); }
+        if (!isinf(lo)) { double v = lo - bt; if (v > btol(lo)) best = better_max(best, ValIdx{bland ? (double)(L.M + L.N - k) : v, 2 * i + 1}); }
+        if (!isinf(up)) { double v = bt - up; if (v > btol(up)) best = better_max(best, ValIdx{bland ? (double)(L.M + L.N - k) : v, 2 * i}); }
     }
     best = block_argmax(best, sv, si);
     const double *drow = T + (size_t)M * ld;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, int B)
         double a = sgn * row[j];
         if (fabs(a) < ptol) continue;
         if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
-            th = fmin(th, (fabs(drow[j]) + TOL_DJ) / fabs(a));
+            th = fmin(th, (fabs(drow[j]) + (bland ? 0.0 : TOL_DJ)) / fabs(a));
     }
     th = block_min(th, sv);
     if (isinf(th)) {                      // no entering candidate: primal infeasible ...
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, int B)
         double a = sgn * row[j];
         if (fabs(a) < ptol) continue;
         if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
-            if (fabs(drow[j]) / fabs(a) <= th) piv = better_max(piv, ValIdx{fabs(a), j});
+            if (fabs(drow[j]) / fabs(a) <= th) piv = better_max(piv, ValIdx{bland ? (double)(L.M + L.N - nh[j]) : fabs(a), j});
     }
     piv = block_argmax(piv, sv, si);
     const int q = piv.i;
@@ -544,6 +547,7 @@ int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double 
     L.Mp1p = (M + 1 + 15) / 16 * 16;
     L.vfirst = var_first; L.vcnt = var_cnt;
     L.maxit = 50 * (M + N) + 1000;
+    L.bland_after = 4 * (M + N) + 200;
     L.slotT = (size_t)L.Mp1 * L.ld;
     h->slots = pool_slots;
     h->cost.assign(cost, cost + N + 1);
