@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--workload", default="S-mid")
     ap.add_argument("--batch", type=int, default=0, help="LPs per GPU per step (default by workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true", help="N=1 only: overlap the LPs of batch k with the cuts of batch k-1 (measured slower on S-mid: the one-batch lag costs more cuts per LP than the overlap saves)")
     ap.add_argument("--policy", type=int, default=0, help="batch selection: 1 newest first, 2 spread (default by workload)")
     ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
     args = ap.parse_args()
@@ -72,9 +73,15 @@ def main():
     if st != 0:
         raise SystemExit("phase 2 start failed: vlp status %d" % st)
 
+    pipe = None
+
     def one_step():
         if world > 1:
             return eng.step_distributed(B * world, dist, device)
+        if pipe is not None:
+            s = pipe.step()
+            s["lps"] = s["lps_solved"]
+            return s
         nl, nt = eng.collect(B, 0, 1)
         rec, piv, ls = eng.solve_local(nl)
         s = eng.apply(rec)
@@ -96,6 +103,10 @@ def main():
         cnt = eng.poly_call("unprocessed", 0)[3]
         if cnt >= B * world or ramp_steps > 200 or (s["n_total"] == 0):
             break
+    if world == 1 and args.pipeline:
+        from bensolve_amd.benson import PipelinedStepper
+        pipe = PipelinedStepper(eng, B)
+        one_step()                       # fills the pipeline (untimed)
     for _ in range(args.warmup):
         one_step()
 
@@ -176,6 +187,7 @@ def main():
             "config": {"workload": "%s (q=%d, n=%d, m=%d dense covering VLP, seed per SURVEY 8d)" % (args.workload, q, n, m),
                        "lp_rows_cols": [m + q + r + 1, n + q + 1], "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "vertex batch sharded over %d GPU(s), one all_gather of cut records per step" % world,
+                       "lp_poly_overlap": pipe is not None,
                        "tableau_slot_bytes": slot_bytes, "pool_slots": 4 * B + 64, "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),

@@ -27,6 +27,10 @@ def _bind(lib):
     lib.bslv_benson_apply.argtypes = [vp, i, vp, vp]
     lib.bslv_benson_step.argtypes = [vp, i, vp, vp]
     lib.bslv_benson_unprocessed_left.argtypes = [vp]
+    lib.bslv_benson_set_pipelined.argtypes = [vp, i]
+    lib.bslv_benson_collect_ctx.argtypes = [vp, i, i, i, i, vp, vp]
+    lib.bslv_benson_solve_local_ctx.argtypes = [vp, i, vp, vp, vp]
+    lib.bslv_benson_apply_ctx.argtypes = [vp, i, i, vp, vp]
     lib.bslv_benson_set_policy.argtypes = [vp, i]
     lib.bslv_benson_totals.argtypes = [vp, vp, vp, vp]
     lib.bslv_benson_poly.argtypes = [vp]
@@ -114,21 +118,24 @@ class BensonEngine:
         out.update(ms_lp=ms[0], ms_poly=ms[1], ms_total=ms[2])
         return out
 
-    def collect(self, max_batch, rank=0, world=1):
+    def set_pipelined(self, on):
+        check(self.lib.bslv_benson_set_pipelined(self.h, int(on)))
+
+    def collect(self, max_batch, rank=0, world=1, ctx=0):
         nl, nt = ctypes.c_int(), ctypes.c_int()
-        check(self.lib.bslv_benson_collect(self.h, max_batch, rank, world, ctypes.byref(nl), ctypes.byref(nt)))
+        check(self.lib.bslv_benson_collect_ctx(self.h, ctx, max_batch, rank, world, ctypes.byref(nl), ctypes.byref(nt)))
         return nl.value, nt.value
 
-    def solve_local(self, n_local):
+    def solve_local(self, n_local, ctx=0):
         rec = np.zeros((max(n_local, 1), self.rec_len))
         piv, ls = ctypes.c_int(), ctypes.c_int()
-        check(self.lib.bslv_benson_solve_local(self.h, rec.ctypes.data, ctypes.byref(piv), ctypes.byref(ls)))
+        check(self.lib.bslv_benson_solve_local_ctx(self.h, ctx, rec.ctypes.data, ctypes.byref(piv), ctypes.byref(ls)))
         return rec[:n_local], piv.value, ls.value
 
-    def apply(self, records):
+    def apply(self, records, ctx=0):
         records = np.ascontiguousarray(records, np.float64).reshape(-1, self.rec_len)
         stats = (ctypes.c_long * 5)()
-        check(self.lib.bslv_benson_apply(self.h, len(records), records.ctypes.data, stats))
+        check(self.lib.bslv_benson_apply_ctx(self.h, ctx, len(records), records.ctypes.data, stats))
         return dict(zip(("lps", "cuts", "redundant", "confirmed", "failed"), list(stats)))
 
     def totals(self):
@@ -156,6 +163,61 @@ class BensonEngine:
         st = self.apply(allrec)
         st.update(n_local=n_local, n_total=n_total, pivots=piv, lockstep=ls)
         return st
+
+
+class PipelinedStepper:
+    """Single-process software pipeline: the LPs of batch k (LP engine, second host thread; ctypes releases
+    the GIL) overlap with the cut application of batch k-1 (polyhedron engine).  Batch members are marked
+    when collected, so batch k never contains a vertex of batch k-1."""
+
+    def __init__(self, eng, max_batch):
+        self.eng, self.B, self.k, self.pending = eng, max_batch, 0, None
+        eng.set_pipelined(True)
+
+    def step(self):
+        import threading
+        eng, ctx = self.eng, self.k & 1
+        self.k += 1
+        nl, nt = eng.collect(self.B, 0, 1, ctx=ctx)
+        box = {}
+
+        def work():
+            try:
+                box["res"] = eng.solve_local(nl, ctx=ctx)
+            except Exception as e:          # re-raised on the main thread
+                box["err"] = e
+        th = threading.Thread(target=work)
+        th.start()
+        st = dict(lps=0, cuts=0, redundant=0, confirmed=0, failed=0)
+        applied = self.pending is not None
+        try:
+            if self.pending is not None:
+                st = eng.apply(self.pending[1], ctx=self.pending[0])
+        finally:
+            th.join()
+        if "err" in box:
+            raise box["err"]
+        rec, piv, ls = box["res"]
+        self.pending = (ctx, rec) if nl else None
+        st.update(n_local=nl, n_total=nt, pivots=piv, lockstep=ls, lps_solved=nl, applied=applied)
+        return st
+
+    def flush(self):
+        st = None
+        if self.pending is not None:
+            st = self.eng.apply(self.pending[1], ctx=self.pending[0])
+            self.pending = None
+        return st
+
+    def run(self, max_steps=100000):
+        """to termination: nothing left to collect and nothing pending"""
+        steps = 0
+        while steps < max_steps:
+            s = self.step()
+            steps += 1
+            if s["n_total"] == 0 and not s["applied"]:      # nothing collected and no cuts applied since: done
+                break
+        return steps
 
 
 def shard_capacity(n_total, world):

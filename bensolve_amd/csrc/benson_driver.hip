@@ -14,6 +14,7 @@
 #include <chrono>
 #include <deque>
 #include <unordered_map>
+#include <mutex>
 
 extern "C" {
 int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
@@ -36,10 +37,15 @@ struct bslv_benson {
     std::unordered_map<int, int> facet_slot;
     std::vector<int> facet_owner;                     // by facet id: rank that solved its LP (-1 unknown)
     bool started = false;
-    // current batch (after collect)
-    std::vector<int> b_idx, b_parent, b_owner;        // whole batch (all ranks)
-    std::vector<double> b_val;
-    std::vector<int> l_pos, l_slot;                   // local shard: position in batch, dst slot
+    // batch contexts (after collect).  Two of them so that the LPs of batch k can run (on the LP engine's
+    // stream, from a second host thread) while the cuts of batch k-1 are applied (polyhedron engine)
+    struct BatchCtx {
+        std::vector<int> b_idx, b_parent, b_owner;    // whole batch (all ranks)
+        std::vector<double> b_val;
+        std::vector<int> l_pos, l_slot;               // local shard: position in batch, dst slot
+    } ctx[2];
+    std::mutex slot_mu;                               // tableau-slot bookkeeping is shared by solve_local and apply
+    int mark_at_collect = 0;                          // pipelined mode: batch members get the sltn mark when collected
     int rank = 0, world = 1;
     int unprocessed_left = 0;
     int policy = 1;                                   // 1: newest vertices first (depth first), 2: spread over the whole queue
@@ -158,13 +164,19 @@ int bslv_benson_start(bslv_benson *h, int *vlp_status)
 
 // Select the next batch (the newest max_batch unprocessed elements; directions are only marked,
 // bslv_algs.c:1036-1040) and deal it to ranks.  n_local = LPs this rank will solve.
+int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, int world, int *n_local, int *n_total);
 int bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int *n_local, int *n_total)
 {
-    if (!h || !h->started || max_batch < 1 || world < 1 || rank < 0 || rank >= world || !n_local || !n_total) {
+    return bslv_benson_collect_ctx(h, 0, max_batch, rank, world, n_local, n_total);
+}
+int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, int world, int *n_local, int *n_total)
+{
+    if (!h || !h->started || max_batch < 1 || world < 1 || rank < 0 || rank >= world || !n_local || !n_total || ctx < 0 || ctx > 1) {
         set_error("bslv_benson_collect: bad argument / not started");
         return BSLV_E_ARG;
     }
     const int q = h->q;
+    bslv_benson::BatchCtx &B = h->ctx[ctx];
     h->rank = rank; h->world = world;
     int rc, cnt = 0;
     for (;;) {
@@ -174,37 +186,40 @@ int bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int 
         std::vector<double> val((size_t)nb * q);
         if (nb && (rc = bslv_poly_unprocessed2(h->poly, nb, h->policy, idx.data(), val.data(), ideal.data(), parent.data(), &cnt))) return rc;
         std::vector<int> dirs;
-        h->b_idx.clear(); h->b_val.clear(); h->b_parent.clear();
+        B.b_idx.clear(); B.b_val.clear(); B.b_parent.clear();
         for (int k = 0; k < nb; k++) {
             if (ideal[k]) { dirs.push_back(idx[k]); continue; }
-            h->b_idx.push_back(idx[k]);
-            h->b_parent.push_back(parent[k]);
-            h->b_val.insert(h->b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
+            B.b_idx.push_back(idx[k]);
+            B.b_parent.push_back(parent[k]);
+            B.b_val.insert(B.b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
         }
         if (!dirs.empty() && (rc = bslv_poly_mark(h->poly, (int)dirs.size(), dirs.data()))) return rc;
         h->unprocessed_left = cnt - nb;
-        if (!h->b_idx.empty() || dirs.empty()) break;     // only directions in this window: look again
+        if (!B.b_idx.empty() || dirs.empty()) break;     // only directions in this window: look again
     }
-    const int nb = (int)h->b_idx.size();
+    const int nb = (int)B.b_idx.size();
+    // pipelined mode: the batch is 'being processed' from now on, so the next collect skips it (a vertex that gets a
+    // cut is removed by that cut; one that does not is confirmed -- either way the mark is final)
+    if (h->mark_at_collect && nb && (rc = bslv_poly_mark(h->poly, nb, B.b_idx.data()))) return rc;
     // deal to ranks: owner of the parent cut if known and not overloaded, else least loaded
-    h->b_owner.assign(nb, 0);
+    B.b_owner.assign(nb, 0);
     std::vector<int> load(world, 0);
     const int cap = (nb + world - 1) / world + std::max(1, nb / (4 * world));
     for (int k = 0; k < nb; k++) {
-        int f = h->b_parent[k];
+        int f = B.b_parent[k];
         int o = (f >= 0 && f < (int)h->facet_owner.size()) ? h->facet_owner[f] : -1;
         if (o < 0 || o >= world || load[o] >= cap) o = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        h->b_owner[k] = o;
+        B.b_owner[k] = o;
         load[o]++;
     }
-    h->l_pos.clear();
-    for (int k = 0; k < nb; k++) if (h->b_owner[k] == rank) h->l_pos.push_back(k);
-    *n_local = (int)h->l_pos.size();
+    B.l_pos.clear();
+    for (int k = 0; k < nb; k++) if (B.b_owner[k] == rank) B.l_pos.push_back(k);
+    *n_local = (int)B.l_pos.size();
     *n_total = nb;
     return 0;
 }
 
-static int take_slot(bslv_benson *h)
+static int take_slot(bslv_benson *h)      // caller holds slot_mu
 {
     if (h->free_slots.empty()) {
         // evict the oldest parents (FIFO); their children fall back to the root tableau
@@ -224,10 +239,16 @@ static int take_slot(bslv_benson *h)
 
 // Solve this rank's shard.  records: n_local x (q+5) doubles
 //   [source slot, LP status, add (z > eps), z, y*_1..y*_q, owner rank]   
+int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *pivots_out, int *lockstep_out);
 int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, int *lockstep_out)
 {
-    if (!h || !h->started) { set_error("bslv_benson_solve_local: not started"); return BSLV_E_STATE; }
-    const int q = h->q, r = h->r, nl = (int)h->l_pos.size(), RL = rec_len(h);
+    return bslv_benson_solve_local_ctx(h, 0, records, pivots_out, lockstep_out);
+}
+int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *pivots_out, int *lockstep_out)
+{
+    if (!h || !h->started || ctx < 0 || ctx > 1) { set_error("bslv_benson_solve_local: not started"); return BSLV_E_STATE; }
+    bslv_benson::BatchCtx &B = h->ctx[ctx];
+    const int q = h->q, r = h->r, nl = (int)B.l_pos.size(), RL = rec_len(h);
     if (pivots_out) *pivots_out = 0;
     if (lockstep_out) *lockstep_out = 0;
     if (nl == 0) return 0;
@@ -235,7 +256,8 @@ int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, in
     if (nl > h->pool_slots - 1) { set_error("batch shard (%d) larger than the tableau pool (%d)", nl, h->pool_slots - 1); return BSLV_E_CAPACITY; }
     std::vector<int> src(nl), dst(nl);
     std::vector<double> vlo((size_t)nl * r, -INFINITY), vup((size_t)nl * r);
-    h->l_slot.assign(nl, -1);
+    B.l_slot.assign(nl, -1);
+    std::unique_lock<std::mutex> lk(h->slot_mu);
     // sources first (eviction below must not take a slot we are about to read)
     // warm-start source: the tableau of the LP whose cut created the vertex; if that was evicted, the
     // resident tableau whose own vertex is nearest (every optimal tableau is dual feasible for every v)
@@ -246,11 +268,11 @@ int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, in
         for (auto &pr : h->parents) if ((c++ % step) == 0 && pr.first >= 0 && h->slot_valid[pr.second]) cand.push_back(pr.second);
     }
     for (int k = 0; k < nl; k++) {
-        int f = h->b_parent[h->l_pos[k]];
+        int f = B.b_parent[B.l_pos[k]];
         auto it = h->facet_slot.find(f);
         src[k] = (it != h->facet_slot.end()) ? it->second : 0;
         if (it == h->facet_slot.end() && !cand.empty()) {
-            const double *v = &h->b_val[(size_t)h->l_pos[k] * q];
+            const double *v = &B.b_val[(size_t)B.l_pos[k] * q];
             double best = INFINITY; int bs = 0;
             for (int s : cand) {
                 const double *u = &h->slot_src[(size_t)s * q];
@@ -275,8 +297,8 @@ int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, in
         }
         if (s < 0) { set_error("tableau pool exhausted (%d slots)", h->pool_slots); return BSLV_E_NOMEM; }
         dst[k] = s;
-        h->l_slot[k] = s;
-        const double *v = &h->b_val[(size_t)h->l_pos[k] * q];
+        B.l_slot[k] = s;
+        const double *v = &B.b_val[(size_t)B.l_pos[k] * q];
         memcpy(&h->slot_src[(size_t)s * q], v, q * sizeof(double));
         h->slot_valid[s] = 1;
         for (int j = 0; j < r; j++) {                   // rows->ub[j] = R_j . v   (bslv_algs.c:1041-1046)
@@ -285,6 +307,7 @@ int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, in
             vup[(size_t)k * r + j] = ub;
         }
     }
+    lk.unlock();
     std::vector<int> st(nl), it(nl);
     int rc;
     if ((rc = bslv_lpq_solve_batch(h->lp, nl, src.data(), dst.data(), vlo.data(), vup.data(), st.data(), it.data()))) return rc;
@@ -295,7 +318,7 @@ int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, in
     long piv = 0;
     for (int k = 0; k < nl; k++) {
         double *rec = records + (size_t)k * RL;
-        rec[0] = h->b_idx[h->l_pos[k]];
+        rec[0] = B.b_idx[B.l_pos[k]];
         rec[1] = st[k];
         rec[3] = zz[k];
         double last = 0;
@@ -316,9 +339,15 @@ int bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, in
 
 // Apply ALL ranks' records (any order in; applied in ascending source slot).  stats (may be NULL):
 // [0] LPs, [1] cuts applied, [2] redundant cuts, [3] confirmed vertices, [4] LP failures
+int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *records, long *stats);
 int bslv_benson_apply(bslv_benson *h, int nrec, const double *records, long *stats)
 {
-    if (!h || !h->started || nrec < 0 || (nrec > 0 && !records)) return BSLV_E_ARG;
+    return bslv_benson_apply_ctx(h, 0, nrec, records, stats);
+}
+int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *records, long *stats)
+{
+    if (!h || !h->started || nrec < 0 || (nrec > 0 && !records) || ctx < 0 || ctx > 1) return BSLV_E_ARG;
+    bslv_benson::BatchCtx &B = h->ctx[ctx];
     const int q = h->q, RL = rec_len(h);
     std::vector<int> order(nrec);
     for (int k = 0; k < nrec; k++) order[k] = k;
@@ -340,11 +369,12 @@ int bslv_benson_apply(bslv_benson *h, int nrec, const double *records, long *sta
     const int f0 = bslv_poly_ndual(h->poly);
     if (ncut && (rc = bslv_poly_add_cuts(h->poly, ncut, cuts.data(), nullptr, prc.data()))) return rc;
     // bookkeeping: facet ids f0.. were assigned in this order on every rank
+    std::lock_guard<std::mutex> lk(h->slot_mu);
     h->facet_owner.resize(f0 + ncut, -1);
     long applied = 0;
     // local slot of a record: position in this rank's shard
     std::unordered_map<int, int> slot_of_src;
-    for (size_t k = 0; k < h->l_pos.size(); k++) slot_of_src[h->b_idx[h->l_pos[k]]] = h->l_slot[k];
+    for (size_t k = 0; k < B.l_pos.size(); k++) slot_of_src[B.b_idx[B.l_pos[k]]] = B.l_slot[k];
     for (int c = 0; c < ncut; c++) {
         const double *rec = records + (size_t)cut_src[c] * RL;
         const int owner = (int)rec[4 + q], f = f0 + c;
@@ -360,7 +390,7 @@ int bslv_benson_apply(bslv_benson *h, int nrec, const double *records, long *sta
         }
     }
     for (auto &kv : slot_of_src) h->free_slots.push_back(kv.second);    // confirmed vertices: tableau not needed again
-    h->l_pos.clear(); h->l_slot.clear();
+    B.l_pos.clear(); B.l_slot.clear();
     h->tot_lps += nrec;
     h->tot_cuts += applied;
     if (stats) { stats[0] = nrec; stats[1] = applied; stats[2] = ncut - applied; stats[3] = (long)confirmed.size(); stats[4] = nfail; }
@@ -389,6 +419,12 @@ int bslv_benson_step(bslv_benson *h, int max_batch, long *stats, double *ms)
 }
 
 int bslv_benson_unprocessed_left(const bslv_benson *h) { return h ? h->unprocessed_left : 0; }
+int bslv_benson_set_pipelined(bslv_benson *h, int on)
+{
+    if (!h) return BSLV_E_ARG;
+    h->mark_at_collect = on ? 1 : 0;
+    return 0;
+}
 int bslv_benson_set_policy(bslv_benson *h, int policy)
 {
     if (!h || policy < 1 || policy > 2) return BSLV_E_ARG;

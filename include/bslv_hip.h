@@ -158,6 +158,12 @@ int  bslv_benson_record_len(const bslv_benson *h);             /* q + 5 doubles 
 int  bslv_benson_solve_local(bslv_benson *h, double *records, int *pivots_out, int *lockstep_out);
 int  bslv_benson_apply(bslv_benson *h, int nrec, const double *records, long *stats /* 5, may be NULL */);
 int  bslv_benson_step(bslv_benson *h, int max_batch, long *stats /* 8 */, double *ms /* 3 */);
+/* two batch contexts (ctx 0/1): the LPs of batch k (solve_local_ctx, may run on a second host thread) overlap with
+ * the cut application of batch k-1 (apply_ctx).  set_pipelined(1): batch members are marked when collected. */
+int  bslv_benson_set_pipelined(bslv_benson *h, int on);
+int  bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, int world, int *n_local, int *n_total);
+int  bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *pivots_out, int *lockstep_out);
+int  bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *records, long *stats);
 int  bslv_benson_unprocessed_left(const bslv_benson *h);
 /* batch selection: 1 = newest vertices first (default), 2 = spread evenly over the unprocessed queue */
 int  bslv_benson_set_policy(bslv_benson *h, int policy);

@@ -155,3 +155,23 @@ def test_two_ranks_match_single():
     single = ph.canonical(eng.poly_dump(), decimals=6)
     eng.close()
     ph.assert_benson_results_agree(ph.canonical(dict(d0), decimals=6), single)
+
+
+@pytest.mark.parametrize("m,n,q,seed,batch", [(30, 15, 3, 5, 16), (60, 30, 3, 7, 64)])
+def test_pipelined_lp_poly_overlap_matches_oracle(m, n, q, seed, batch):
+    """LPs of batch k on a second host thread while the cuts of batch k-1 are applied"""
+    from bensolve_amd.benson import PipelinedStepper
+    prob = synth.covering_vlp(m, n, q, seed)
+    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=1e-7)
+    fp.dual_adjacency()
+    exp = ph.canonical(fp.dump(), decimals=6)
+    fp.close()
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=max(8 * batch, 128))
+    assert eng.start() == 0
+    PipelinedStepper(eng, batch).run()
+    eng.poly_call("dual_adjacency")
+    got = ph.canonical(eng.poly_dump(), decimals=6)
+    d = eng.poly_dump()
+    assert np.all(d["ps"][d["pu"].astype(bool)] == 1)         # every live element was processed
+    eng.close()
+    ph.assert_benson_results_agree(got, exp)
