@@ -194,12 +194,12 @@ __device__ __forceinline__ double block_min(double v, double *sv)
 // ---- k_select: dual simplex choice of (leaving row r, entering column q) for each running LP.
 //      Same rules as oracle/lp_dense.c dual_simplex(): largest bound violation, Harris two-pass
 //      ratio test with the largest |pivot| among the ties. ----
-__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, int B)
+__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact)
 {
     __shared__ double sv[NT / WAVE];
     __shared__ int si[NT / WAVE];
-    int b = blockIdx.x;
-    if (b >= B) return;
+    if ((int)blockIdx.x >= nact) return;
+    const int b = active[blockIdx.x];          // compacted list of the LPs still running
     if (Bv.status[b] != ST_RUNNING) return;
     const int tid = threadIdx.x;
     int slot = Bv.dst[b];
@@ -314,11 +314,11 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, int B)
 //      row r: T[r][j] = -prow[j] * p (j != q), T[r][q] = p, beta[r] = enter_val.
 //      Row M (reduced costs, objective value) is updated by the same formula.
 //      Algorithmic traffic: one read + one write of the tableau = 16 B per element per pivot. ----
-__global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int B)
+__global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, const int *active, int nact, int tr /* rows per workgroup: 8, 16 or 32 */)
 {
     extern __shared__ double s_prow[];
-    int b = blockIdx.y;
-    if (b >= B) return;
+    if ((int)blockIdx.y >= nact) return;
+    const int b = active[blockIdx.y];
     if (Bv.status[b] != ST_RUNNING) return;
     const int mode = Bv.mode[b];
     if (mode == MODE_NONE) return;
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int B)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (mode == MODE_REFRESH) {
         const double2 *x2 = reinterpret_cast<const double2 *>(L.xN + (size_t)slot * ld);
-        for (int rr = wave; rr < TR; rr += NT / WAVE) {
-            int i = blockIdx.x * TR + rr;
+        for (int rr = wave; rr < tr; rr += NT / WAVE) {
+            int i = blockIdx.x * tr + rr;
             if (i >= L.Mp1) break;
             const double2 *t2 = reinterpret_cast<const double2 *>(T + (size_t)i * ld);
             double acc = 0.0;
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int B)
     // each wave owns TR/4 consecutive rows and streams them two at a time: the multipliers f of both rows
     // are fetched first, then both rows' loads are in flight before the first store (more bytes in
     // flight per CU than one row at a time)
-    constexpr int RPW = TR / (NT / WAVE);
-    const int row0 = blockIdx.x * TR + wave * RPW;
+    const int RPW = tr / (NT / WAVE);
+    const int row0 = blockIdx.x * tr + wave * RPW;
     for (int rr = 0; rr < RPW; rr += 2) {
         const int i0 = row0 + rr, i1 = i0 + 1;
         if (i0 >= L.Mp1) break;
@@ -441,6 +441,7 @@ struct bslv_lpq {
     // batch buffers
     int Bcap = 0;
     int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
+    int *active_d = nullptr, *active_h = nullptr;       // compacted indices of the LPs still running (device / pinned)
     double *vlo_d = nullptr, *vup_d = nullptr, *prow_d = nullptr, *out_d = nullptr;
     size_t out_cap = 0;
     PivDesc *desc_d = nullptr;
@@ -458,9 +459,10 @@ static int ensure_batch(bslv_lpq *h, int B)
     if (B <= h->Bcap) return 0;
     int cap = std::max(B, h->Bcap * 2);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
-    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
+    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
+    if (h->active_h) (void)hipHostFree(h->active_h);
     h->Bcap = 0;
     HIP_TRY(hipMalloc(&h->src_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->dst_d, cap * sizeof(int)));
@@ -474,6 +476,8 @@ static int ensure_batch(bslv_lpq *h, int B)
     HIP_TRY(hipMalloc(&h->prow_d, (size_t)cap * h->L.ld * sizeof(double)));
     HIP_TRY(hipMalloc(&h->desc_d, cap * sizeof(PivDesc)));
     HIP_TRY(hipHostMalloc(&h->status_h, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->active_d, cap * sizeof(int)));
+    HIP_TRY(hipHostMalloc(&h->active_h, cap * sizeof(int)));
     h->Bcap = cap;
     return 0;
 }
@@ -591,8 +595,9 @@ void bslv_lpq_destroy(bslv_lpq *h)
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
-    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
+    if (h->active_h) (void)hipHostFree(h->active_h);
     for (auto &e : h->evpool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -663,11 +668,13 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     HIP_TRY(hipGetLastError());
     const size_t lds = (size_t)L.ld * sizeof(double);
     int it = 0, chunk = 4, running = B;
+    for (int b = 0; b < B; b++) h->active_h[b] = b;
+    HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, B * sizeof(int), hipMemcpyHostToDevice, s));
     size_t nev = 0;
     h->last_update_ms = 0;
     while (running > 0 && it < L.maxit + 8) {
         for (int c = 0; c < chunk; c++, it++) {
-            hipLaunchKernelGGL(k_select, dim3(B), dim3(NT), 0, s, L, bv, B);
+            hipLaunchKernelGGL(k_select, dim3(running), dim3(NT), 0, s, L, bv, h->active_d, running);
             if (h->profile) {
                 if (nev == h->evpool.size()) {
                     hipEvent_t a, b2;
@@ -676,14 +683,17 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
                 }
                 HIP_TRY(hipEventRecord(h->evpool[nev].first, s));
             }
-            hipLaunchKernelGGL(k_update, dim3(tiles, B), dim3(NT), lds, s, L, bv, B);
+            // few LPs left: smaller row tiles keep >= ~2k workgroups in flight
+            const int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : 8);
+            hipLaunchKernelGGL(k_update, dim3((L.Mp1 + tr - 1) / tr, running), dim3(NT), lds, s, L, bv, h->active_d, running, tr);
             if (h->profile) { HIP_TRY(hipEventRecord(h->evpool[nev].second, s)); nev++; }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->status_h, h->status_d, B * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         running = 0;
-        for (int b = 0; b < B; b++) running += (h->status_h[b] == ST_RUNNING);
+        for (int b = 0; b < B; b++) if (h->status_h[b] == ST_RUNNING) h->active_h[running++] = b;
+        if (running) HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, running * sizeof(int), hipMemcpyHostToDevice, s));
         if (chunk < 16) chunk *= 2;
     }
     if (status) for (int b = 0; b < B; b++) status[b] = h->status_h[b] == ST_RUNNING ? BSLV_LP_UNDEFINED : h->status_h[b];
