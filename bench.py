@@ -114,7 +114,7 @@ def main():
     rounds0 = eng.poly_call("rounds_run")
     nv0 = eng.poly_call("counts")["new_vertices"]
     pt0 = eng.poly_call("counts")["pair_tests"]
-    lps = cuts = pivots = lockstep = 0
+    lps = cuts = pivots = lockstep = redundant = confirmed = 0
     upd_ms = 0.0
     lp_ms = 0.0
     sync()
@@ -123,6 +123,8 @@ def main():
         s = one_step()
         lps += s["lps"]
         cuts += s["cuts"]
+        redundant += s.get("redundant", 0)
+        confirmed += s.get("confirmed", 0)
         pivots += s["pivots"]
         lockstep += s["lockstep"]
         ls = eng.lp_call("last_stats")
@@ -189,7 +191,7 @@ def main():
                        "parallelism": "vertex batch sharded over %d GPU(s), one all_gather of cut records per step" % world,
                        "lp_poly_overlap": pipe is not None,
                        "tableau_slot_bytes": slot_bytes, "pool_slots": 4 * B + 64, "ramp_steps_untimed": ramp_steps},
-            "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts,
+            "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
             "live_vertices": live, "poly_rounds": eng.poly_call("rounds_run") - rounds0, "lp_ms_rank0": round(lp_ms, 2), "update_kernel_ms_rank0": round(upd_ms, 2),
             "roofline": roofline, "cpu_baseline": cpu,

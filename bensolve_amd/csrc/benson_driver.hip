@@ -15,6 +15,8 @@
 #include <deque>
 #include <unordered_map>
 #include <mutex>
+#include <unordered_set>
+#include <string>
 
 extern "C" {
 int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
@@ -354,11 +356,23 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     std::sort(order.begin(), order.end(), [&](int a, int b) { return records[(size_t)a * RL] < records[(size_t)b * RL]; });
     std::vector<int> confirmed, cut_src;
     std::vector<double> cuts;
-    long nfail = 0;
+    std::unordered_set<std::string> dedupe;
+    long nfail = 0, nduplicate = 0;
     for (int k : order) {
         const double *rec = records + (size_t)k * RL;
         if ((int)rec[1] != BSLV_LP_OPTIMAL) { nfail++; continue; }
-        if (rec[2] != 0.0) { cuts.insert(cuts.end(), rec + 4, rec + 4 + q); cut_src.push_back(k); }
+        if (rec[2] != 0.0) {
+            // sibling vertices (children of one cut) mostly see the SAME facet of the upper image: an exact duplicate of
+            // a cut already in this batch has no violating vertex once the first copy is applied (the reference's
+            // poly__add_vrtx returns EXIT_FAILURE for it, bslv_poly.c:130-136); it is dropped here, on the host, instead
+            // of paying a classification pass.  Key: coordinates relative to max(1,|y*|), rounded to 1e-11.
+            double sc = 1.0;
+            for (int kk = 0; kk < q; kk++) sc = std::max(sc, std::fabs(rec[4 + kk]));
+            std::string key((size_t)q * sizeof(long long), '\0');
+            for (int kk = 0; kk < q; kk++) { long long v = std::llround(rec[4 + kk] / sc * 1e11); memcpy(&key[(size_t)kk * sizeof(long long)], &v, sizeof v); }
+            if (!dedupe.insert(key).second) { nduplicate++; continue; }
+            cuts.insert(cuts.end(), rec + 4, rec + 4 + q); cut_src.push_back(k);
+        }
         else confirmed.push_back((int)rec[0]);                                                           // :1074-1079
     }
     int rc;
@@ -393,7 +407,7 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     B.l_pos.clear(); B.l_slot.clear();
     h->tot_lps += nrec;
     h->tot_cuts += applied;
-    if (stats) { stats[0] = nrec; stats[1] = applied; stats[2] = ncut - applied; stats[3] = (long)confirmed.size(); stats[4] = nfail; }
+    if (stats) { stats[0] = nrec; stats[1] = applied; stats[2] = ncut - applied + nduplicate; stats[3] = (long)confirmed.size(); stats[4] = nfail; }
     return 0;
 }
 

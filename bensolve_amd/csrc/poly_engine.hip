@@ -263,6 +263,38 @@ __device__ __forceinline__ int isect3_count(const int *a, int na, const int *b, 
     return n;
 }
 
+// Short lists (the common case: a vertex of a simple polytope lies on d facets) are fetched with 16
+// independent predicated loads -- ONE memory latency instead of a dependent chain of loads through the
+// merge loop -- and intersected in registers.  Longer lists take the merge loop.
+constexpr int LCAP = 16;
+__device__ __forceinline__ void load_list(const int *p, int n, int (&out)[LCAP])
+{
+#pragma unroll
+    for (int k = 0; k < LCAP; k++) out[k] = k < n ? p[k] : 0x7FFFFFFF;
+}
+// bit a of the result: A[a] occurs in B (both sorted, padded with INT_MAX which never matches a < n entry)
+__device__ __forceinline__ unsigned match_mask(const int (&A)[LCAP], int na, const int (&B)[LCAP])
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int a = 0; a < LCAP; a++) {
+        bool hit = false;
+#pragma unroll
+        for (int b = 0; b < LCAP; b++) hit |= (A[a] == B[b]);
+        m |= (unsigned)(hit && a < na) << a;
+    }
+    return m;
+}
+__device__ __forceinline__ int isect_count_fast(const int *a, int na, const int *b, int nb)
+{
+    if (na <= LCAP && nb <= LCAP) {
+        int A[LCAP], B[LCAP];
+        load_list(a, na, A); load_list(b, nb, B);
+        return __popc(match_mask(A, na, B));
+    }
+    return isect_count(a, na, b, nb);
+}
+
 // ---------------- E: edges ----------------
 // eflag: 0 dropped, 1 survives, 4 survives and joins a ZERO to a PLUS element, 2 crossing with a MINUS (b PLUS), 3 crossing with b MINUS
 // per element triple: (survive, cross, new incidence-list length)
@@ -274,7 +306,7 @@ __device__ __forceinline__ Tri edge_triple(const PolyView &P, const int2 e, unsi
     if ((ca == -1 && cb == 1) || (ca == 1 && cb == -1)) {
         f = (ca == -1) ? 2 : 3;
         t.b = 1;
-        t.c = isect_count(P.pool + P.inc_off[e.x], P.inc_len[e.x], P.pool + P.inc_off[e.y], P.inc_len[e.y]) + 1;
+        t.c = isect_count_fast(P.pool + P.inc_off[e.x], P.inc_len[e.x], P.pool + P.inc_off[e.y], P.inc_len[e.y]) + 1;
     } else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = (ca == 0 || cb == 0) ? 4 : 1; t.a = 1; }
     *fl = f;
     return t;
@@ -291,6 +323,9 @@ __global__ __launch_bounds__(PB) void k_edge_flags(PolyView P, const int2 *E, in
 }
 // writes survivors to Enew[0..nsurv), creates vertex nv0+crossidx with its incidence list at
 // pool[pool0 + off), its edge at Enew[nsurv + crossidx], and marks keep[] for ZERO-PLUS edges
+// D = compile-time dimension (0 = run-time P.d): keeps the coordinate arrays in registers -- with a run-time
+// bound they are indexed dynamically and land in scratch memory (the kernel ran 10x slower)
+template <int D>
 __global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, const int2 *E, int ne, const unsigned char *eflag,
                                                    const Tri *bpre, const Tri *totals, int2 *Enew, int nv0, unsigned pool0)
 {
@@ -304,14 +339,14 @@ __global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, 
         if (f == 1 || f == 4) t.a = 1;
         else if (f >= 2) {
             t.b = 1;
-            t.c = isect_count(P.pool + P.inc_off[ed.x], P.inc_len[ed.x], P.pool + P.inc_off[ed.y], P.inc_len[ed.y]) + 1;
+            t.c = isect_count_fast(P.pool + P.inc_off[ed.x], P.inc_len[ed.x], P.pool + P.inc_off[ed.y], P.inc_len[ed.y]) + 1;
         }
     }
     Tri tot;
     Tri ex = block_exscan(t, &tot, lds);
     if (e >= ne) return;
     ex = tri_add(ex, bpre[blockIdx.x]);
-    const int d = P.d;
+    const int d = D > 0 ? D : P.d;
     if (f == 1) Enew[ex.a] = ed;          // plain survivor: a streaming copy, no class lookups
     else if (f == 4) {
         Enew[ex.a] = ed;
@@ -323,54 +358,74 @@ __global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, 
         if (z >= 0) {
             const int *A = P.pool + P.inc_off[z], *Bp = P.pool + P.inc_off[pl];
             unsigned char *K = P.keep + P.inc_off[z];
-            int na = P.inc_len[z], nb = P.inc_len[pl], i = 0, j = 0;
-            while (i < na && j < nb) {
-                int x = A[i], y = Bp[j];
-                if (x == y) K[i] = 1;
-                i += (x <= y);
-                j += (y <= x);
+            int na = P.inc_len[z], nb = P.inc_len[pl];
+            if (na <= LCAP && nb <= LCAP) {
+                int RA[LCAP], RB[LCAP];
+                load_list(A, na, RA); load_list(Bp, nb, RB);
+                unsigned m = match_mask(RA, na, RB);
+                while (m) { int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }
+            } else {
+                int i = 0, j = 0;
+                while (i < na && j < nb) {
+                    int x = A[i], y = Bp[j];
+                    if (x == y) K[i] = 1;
+                    i += (x <= y);
+                    j += (y <= x);
+                }
             }
         }
     } else if (f == 2 || f == 3) {
         const int mi = (f == 2) ? ed.x : ed.y, pl = (f == 2) ? ed.y : ed.x;
         const int w = nv0 + ex.b;
         const bool im = P.flag[mi] & F_IDEAL, ip = P.flag[pl] & F_IDEAL;
-        double xm[MAXD], xp[MAXD];
-        for (int k = 0; k < d; k++) { xm[k] = P.X[(size_t)k * P.cap + mi]; xp[k] = P.X[(size_t)k * P.cap + pl]; }
+        constexpr int DD = D > 0 ? D : MAXD;
+        double xm[DD], xp[DD], base[DD], dirv[DD];
+#pragma unroll
+        for (int k = 0; k < DD; k++) { xm[k] = k < d ? P.X[(size_t)k * P.cap + mi] : 0.0; xp[k] = k < d ? P.X[(size_t)k * P.cap + pl] : 0.0; }
         double hb = 0.0, hd = 0.0, a2 = hp.h[d];
         unsigned char nf = F_USED;
-        // new vertex on the edge (bslv_poly.c:597-627); same operation order as oracle/poly_dd.c
+        // new vertex on the edge (bslv_poly.c:597-627); same operation order as oracle/poly_dd.c:
+        // base + mu * dir with (base, dir) = (minus, plus - minus) for two directions, (plus, minus - plus) for two
+        // points, (the point, the direction) otherwise
         if (ip && im) {
-            a2 = 0.0;
-            for (int k = 0; k < d; k++) hd = fma(hp.h[k], xp[k] - xm[k], hd);
-            for (int k = 0; k < d; k++) hb = fma(hp.h[k], xm[k], hb);
-            double mu = (a2 - hb) / hd;
-            for (int k = 0; k < d; k++) P.X[(size_t)k * P.cap + w] = fma(mu, xp[k] - xm[k], xm[k]);
-            nf |= F_IDEAL;
+            a2 = 0.0; nf |= F_IDEAL;
+#pragma unroll
+            for (int k = 0; k < DD; k++) { base[k] = xm[k]; dirv[k] = xp[k] - xm[k]; }
         } else if (!ip && !im) {
-            for (int k = 0; k < d; k++) hd = fma(hp.h[k], xm[k] - xp[k], hd);
-            for (int k = 0; k < d; k++) hb = fma(hp.h[k], xp[k], hb);
-            double mu = (a2 - hb) / hd;
-            for (int k = 0; k < d; k++) P.X[(size_t)k * P.cap + w] = fma(mu, xm[k] - xp[k], xp[k]);
+#pragma unroll
+            for (int k = 0; k < DD; k++) { base[k] = xp[k]; dirv[k] = xm[k] - xp[k]; }
         } else {
-            const double *base = ip ? xm : xp, *dirv = ip ? xp : xm;
-            for (int k = 0; k < d; k++) hd = fma(hp.h[k], dirv[k], hd);
-            for (int k = 0; k < d; k++) hb = fma(hp.h[k], base[k], hb);
-            double mu = (a2 - hb) / hd;
-            for (int k = 0; k < d; k++) P.X[(size_t)k * P.cap + w] = fma(mu, dirv[k], base[k]);
+#pragma unroll
+            for (int k = 0; k < DD; k++) { base[k] = ip ? xm[k] : xp[k]; dirv[k] = ip ? xp[k] : xm[k]; }
         }
+#pragma unroll
+        for (int k = 0; k < DD; k++) if (k < d) hd = fma(hp.h[k], dirv[k], hd);
+#pragma unroll
+        for (int k = 0; k < DD; k++) if (k < d) hb = fma(hp.h[k], base[k], hb);
+        const double mu = (a2 - hb) / hd;
+#pragma unroll
+        for (int k = 0; k < DD; k++) if (k < d) P.X[(size_t)k * P.cap + w] = fma(mu, dirv[k], base[k]);
         P.flag[w] = nf;
         P.cls[w] = 0;
         // incidence = inc(minus) & inc(plus) + new facet (bslv_poly.c:634-665)
         const unsigned off = pool0 + (unsigned)ex.c;
         int *out = P.pool + off;
         const int *A = P.pool + P.inc_off[mi], *Bp = P.pool + P.inc_off[pl];
-        int na = P.inc_len[mi], nb = P.inc_len[pl], i = 0, j = 0, n = 0;
-        while (i < na && j < nb) {
-            int x = A[i], y = Bp[j];
-            if (x == y) out[n++] = x;
-            i += (x <= y);
-            j += (y <= x);
+        int na = P.inc_len[mi], nb = P.inc_len[pl], n = 0;
+        if (na <= LCAP && nb <= LCAP) {
+            int RA[LCAP], RB[LCAP];
+            load_list(A, na, RA); load_list(Bp, nb, RB);
+            const unsigned m = match_mask(RA, na, RB);
+#pragma unroll
+            for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = RA[a];
+        } else {
+            int i = 0, j = 0;
+            while (i < na && j < nb) {
+                int x = A[i], y = Bp[j];
+                if (x == y) out[n++] = x;
+                i += (x <= y);
+                j += (y <= x);
+            }
         }
         out[n++] = facet;
         P.inc_off[w] = off;
@@ -389,7 +444,11 @@ __global__ __launch_bounds__(PB) void k_vert_flags(PolyView P, int nv0, Tri *bsu
     if (i < nv0 && P.cls[i] == 0) {
         const unsigned char *K = P.keep + P.inc_off[i];
         int n = P.inc_len[i], kept = 0;
-        for (int j = 0; j < n; j++) kept += K[j];
+        if (n <= LCAP) {
+#pragma unroll
+            for (int j = 0; j < LCAP; j++) kept += (j < n) ? K[j] : 0;      // independent loads
+        } else
+            for (int j = 0; j < n; j++) kept += K[j];
         t.a = 1; t.c = kept + 1;
     }
     Tri tot;
@@ -402,12 +461,24 @@ __global__ __launch_bounds__(PB) void k_vert_emit(PolyView P, int facet, int nv0
     int i = blockIdx.x * PB + threadIdx.x;
     Tri t{0, 0, 0};
     signed char c = 2;
+    unsigned keptmask = 0;
+    int lst[LCAP];
+    int n = 0;
+    unsigned off_old = 0;
     if (i < nv0) {
         c = P.cls[i];
         if (c == 0) {
-            const unsigned char *K = P.keep + P.inc_off[i];
-            int n = P.inc_len[i], kept = 0;
-            for (int j = 0; j < n; j++) kept += K[j];
+            off_old = P.inc_off[i];
+            n = P.inc_len[i];
+            const unsigned char *K = P.keep + off_old;
+            int kept = 0;
+            if (n <= LCAP) {
+                load_list(P.pool + off_old, n, lst);
+#pragma unroll
+                for (int j = 0; j < LCAP; j++) { unsigned k = (j < n) ? K[j] : 0; keptmask |= (k & 1u) << j; }
+                kept = __popc(keptmask);
+            } else
+                for (int j = 0; j < n; j++) kept += K[j];
             t.a = 1; t.c = kept + 1;
         }
     }
@@ -418,11 +489,14 @@ __global__ __launch_bounds__(PB) void k_vert_emit(PolyView P, int facet, int nv0
     if (c != 0) return;
     ex = tri_add(ex, bpre[blockIdx.x]);
     members[ex.a] = i;
-    const unsigned off_old = P.inc_off[i], off_new = pool0 + (unsigned)ex.c;
-    const int n = P.inc_len[i];
+    const unsigned off_new = pool0 + (unsigned)ex.c;
     int m = 0;
-    for (int j = 0; j < n; j++)
-        if (P.keep[off_old + j]) { P.pool[off_new + m++] = P.pool[off_old + j]; P.keep[off_old + j] = 0; }
+    if (n <= LCAP) {
+#pragma unroll
+        for (int j = 0; j < LCAP; j++) if ((keptmask >> j) & 1u) { P.pool[off_new + m++] = lst[j]; P.keep[off_old + j] = 0; }
+    } else
+        for (int j = 0; j < n; j++)
+            if (P.keep[off_old + j]) { P.pool[off_new + m++] = P.pool[off_old + j]; P.keep[off_old + j] = 0; }
     P.pool[off_new + m++] = facet;
     P.inc_off[i] = off_new;
     P.inc_len[i] = m;
@@ -977,7 +1051,12 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
     if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
     const unsigned pool_e = h->poolused, pool_z = h->poolused + (unsigned)te.c;
     // ---- round B: edge emit, on-plane rebuild, pair flags + scan -> host ----
-    hipLaunchKernelGGL(k_edge_emit, dim3(nbe), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, h->eflag, h->bsum, h->totals + 0, Enew, nv0, pool_e);
+    switch (d) {
+#define CASE(D) case D: hipLaunchKernelGGL(k_edge_emit<D>, dim3(nbe), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, h->eflag, h->bsum, h->totals + 0, Enew, nv0, pool_e); break;
+        CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+    default: hipLaunchKernelGGL(k_edge_emit<0>, dim3(nbe), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, h->eflag, h->bsum, h->totals + 0, Enew, nv0, pool_e); break;
+    }
     hipLaunchKernelGGL(k_vert_flags, dim3(nbv), dim3(PB), 0, s, h->P, nv0, h->bsum);
     const int seqB1 = ++h->mailseq;
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, nbv, h->totals + 1, h->mail_d + 1, (const int *)nullptr, seqB1);
