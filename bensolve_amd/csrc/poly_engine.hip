@@ -285,12 +285,44 @@ __device__ __forceinline__ unsigned match_mask(const int (&A)[LCAP], int na, con
     }
     return m;
 }
+// position of x in the sorted list b[0..nb), or -1 (binary search: log2(nb) dependent loads)
+__device__ __forceinline__ int find_sorted(const int *b, int nb, int x)
+{
+    int lo = 0, hi = nb - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) >> 1, y = b[mid];
+        if (y == x) return mid;
+        if (y < x) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+// bit a: A[a] occurs in the LONG sorted list b.  The extreme directions of an upper image lie on every facet
+// with a zero weight, so their incidence lists grow to thousands of entries; an edge to a direction must not
+// walk such a list linearly (it cost 100-200 us per cut): each of the <= 16 short entries does its own
+// binary search, the 16 searches overlap.
+__device__ __forceinline__ unsigned match_mask_long(const int (&A)[LCAP], int na, const int *b, int nb, int (&posB)[LCAP])
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int a = 0; a < LCAP; a++) {
+        int p = a < na ? find_sorted(b, nb, A[a]) : -1;
+        posB[a] = p;
+        m |= (unsigned)(p >= 0) << a;
+    }
+    return m;
+}
 __device__ __forceinline__ int isect_count_fast(const int *a, int na, const int *b, int nb)
 {
     if (na <= LCAP && nb <= LCAP) {
         int A[LCAP], B[LCAP];
         load_list(a, na, A); load_list(b, nb, B);
         return __popc(match_mask(A, na, B));
+    }
+    if (na <= LCAP || nb <= LCAP) {
+        const bool ashort = na <= nb;
+        int S[LCAP], pos[LCAP];
+        load_list(ashort ? a : b, ashort ? na : nb, S);
+        return __popc(match_mask_long(S, ashort ? na : nb, ashort ? b : a, ashort ? nb : na, pos));
     }
     return isect_count(a, na, b, nb);
 }
@@ -364,6 +396,17 @@ __global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, 
                 load_list(A, na, RA); load_list(Bp, nb, RB);
                 unsigned m = match_mask(RA, na, RB);
                 while (m) { int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }
+            } else if (na <= LCAP) {                 // ZERO element short, PLUS neighbour long
+                int RA[LCAP], pos[LCAP];
+                load_list(A, na, RA);
+                unsigned m = match_mask_long(RA, na, Bp, nb, pos);
+                while (m) { int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }
+            } else if (nb <= LCAP) {                 // ZERO element long (a direction), PLUS neighbour short
+                int RB[LCAP], pos[LCAP];
+                load_list(Bp, nb, RB);
+                unsigned m = match_mask_long(RB, nb, A, na, pos);
+#pragma unroll
+                for (int b2 = 0; b2 < LCAP; b2++) if ((m >> b2) & 1u) K[pos[b2]] = 1;
             } else {
                 int i = 0, j = 0;
                 while (i < na && j < nb) {
@@ -418,6 +461,13 @@ __global__ __launch_bounds__(PB) void k_edge_emit(PolyView P, Hp hp, int facet, 
             const unsigned m = match_mask(RA, na, RB);
 #pragma unroll
             for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = RA[a];
+        } else if (na <= LCAP || nb <= LCAP) {       // one end is a direction with a long list
+            const bool ashort = na <= nb;
+            int S[LCAP], pos[LCAP];
+            load_list(ashort ? A : Bp, ashort ? na : nb, S);
+            const unsigned m = match_mask_long(S, ashort ? na : nb, ashort ? Bp : A, ashort ? nb : na, pos);
+#pragma unroll
+            for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = S[a];
         } else {
             int i = 0, j = 0;
             while (i < na && j < nb) {
