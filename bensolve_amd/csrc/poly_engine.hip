@@ -267,6 +267,7 @@ __device__ __forceinline__ int isect3_count(const int *a, int na, const int *b, 
 // independent predicated loads -- ONE memory latency instead of a dependent chain of loads through the
 // merge loop -- and intersected in registers.  Longer lists take the merge loop.
 constexpr int LCAP = 16;
+constexpr int LONGN = 64;      // lists longer than this are processed by a whole wave
 __device__ __forceinline__ void load_list(const int *p, int n, int (&out)[LCAP])
 {
 #pragma unroll
@@ -491,15 +492,35 @@ __global__ __launch_bounds__(PB) void k_vert_flags(PolyView P, int nv0, Tri *bsu
     __shared__ Tri lds[16];
     int i = blockIdx.x * PB + threadIdx.x;
     Tri t{0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    unsigned off = 0;
+    int n = 0;
+    bool zero = false;
     if (i < nv0 && P.cls[i] == 0) {
-        const unsigned char *K = P.keep + P.inc_off[i];
-        int n = P.inc_len[i], kept = 0;
+        zero = true;
+        off = P.inc_off[i];
+        n = P.inc_len[i];
+        const unsigned char *K = P.keep + off;
+        int kept = 0;
         if (n <= LCAP) {
 #pragma unroll
             for (int j = 0; j < LCAP; j++) kept += (j < n) ? K[j] : 0;      // independent loads
-        } else
+        } else if (n <= LONGN)
             for (int j = 0; j < n; j++) kept += K[j];
         t.a = 1; t.c = kept + 1;
+    }
+    // long lists (extreme directions): the wave counts the kept entries together
+    unsigned long long todo = __ballot(zero && n > LONGN);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const unsigned oo = __shfl(off, src, WAVE);
+        const int nn = __shfl(n, src, WAVE);
+        int cnt = 0;
+        for (int j = lane; j < nn; j += WAVE) cnt += P.keep[oo + j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+        if (lane == src) t.c = cnt + 1;
     }
     Tri tot;
     (void)block_exscan(t, &tot, lds);
@@ -527,19 +548,54 @@ __global__ __launch_bounds__(PB) void k_vert_emit(PolyView P, int facet, int nv0
 #pragma unroll
                 for (int j = 0; j < LCAP; j++) { unsigned k = (j < n) ? K[j] : 0; keptmask |= (k & 1u) << j; }
                 kept = __popc(keptmask);
-            } else
+            } else if (n <= LONGN)
                 for (int j = 0; j < n; j++) kept += K[j];
             t.a = 1; t.c = kept + 1;
         }
     }
+    const int lane = threadIdx.x & 63;
+    const bool longz = (c == 0) && n > LONGN;
+    {   // long lists: kept count by the whole wave (same value k_vert_flags produced)
+        unsigned long long todo = __ballot(longz);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned oo = __shfl(off_old, src, WAVE);
+            const int nn = __shfl(n, src, WAVE);
+            int cnt = 0;
+            for (int j = lane; j < nn; j += WAVE) cnt += P.keep[oo + j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+            if (lane == src) t.c = cnt + 1;
+        }
+    }
     Tri tot;
     Tri ex = block_exscan(t, &tot, lds);
+    ex = tri_add(ex, bpre[blockIdx.x]);
+    const unsigned off_new = pool0 + (unsigned)ex.c;
+    {   // long lists: ordered compaction by the whole wave (ballot ranks), then the new facet
+        unsigned long long todo = __ballot(longz);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned oo = __shfl(off_old, src, WAVE), on = __shfl(off_new, src, WAVE);
+            const int nn = __shfl(n, src, WAVE), vv = __shfl(i, src, WAVE);
+            int base = 0;
+            for (int j0 = 0; j0 < nn; j0 += WAVE) {
+                const int j = j0 + lane;
+                const bool k = j < nn && P.keep[oo + j];
+                const unsigned long long bm = __ballot(k);
+                if (k) { P.pool[on + base + __popcll(bm & ((1ull << lane) - 1ull))] = P.pool[oo + j]; P.keep[oo + j] = 0; }
+                base += __popcll(bm);
+            }
+            if (lane == 0) { P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; }
+        }
+    }
     if (i >= nv0) return;
     if (c == -1) { P.flag[i] &= ~F_USED; return; }
     if (c != 0) return;
-    ex = tri_add(ex, bpre[blockIdx.x]);
     members[ex.a] = i;
-    const unsigned off_new = pool0 + (unsigned)ex.c;
+    if (longz) return;
     int m = 0;
     if (n <= LCAP) {
 #pragma unroll
@@ -645,34 +701,68 @@ __global__ __launch_bounds__(PB) void k_pair_flags(PolyView P, const int *member
 // 8 lanes per member: list entries and bit words are spread over the lanes, so the dependent
 // global accesses of one member overlap instead of forming one serial chain
 constexpr int LPM = 8;
+// members with long lists (an extreme direction lies on thousands of facets) are swept by the whole wave
 __global__ __launch_bounds__(PB) void k_local_ids(PolyView P, const int *members, int nm, int W, int stamp, int *fstamp, int *flocal,
                                                    int *nlocal, unsigned long long *bits)
 {
-    int t = blockIdx.x * PB + threadIdx.x;
-    int m = t / LPM, sub = t % LPM;
-    if (m >= nm) return;
-    for (int w = sub; w < W; w += LPM) bits[(size_t)w * nm + m] = 0ull;
-    int v = members[m];
-    const int *L = P.pool + P.inc_off[v];
-    int n = P.inc_len[v];
-    for (int j = sub; j < n; j += LPM) {
-        int g = L[j];
-        if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= stamp) continue;
-        int old = atomicMax(&fstamp[g], stamp);
-        if (old < stamp) flocal[g] = atomicAdd(nlocal, 1);
+    const int t = blockIdx.x * PB + threadIdx.x, lane = threadIdx.x & 63;
+    const int m = t / LPM, sub = t % LPM;
+    const bool valid = m < nm;
+    int v = -1, n = 0;
+    if (valid) {
+        for (int w = sub; w < W; w += LPM) bits[(size_t)w * nm + m] = 0ull;
+        v = members[m];
+        n = P.inc_len[v];
+    }
+    const bool longm = valid && n > LONGN;
+    if (valid && !longm) {
+        const int *L = P.pool + P.inc_off[v];
+        for (int j = sub; j < n; j += LPM) {
+            int g = L[j];
+            if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= stamp) continue;
+            int old = atomicMax(&fstamp[g], stamp);
+            if (old < stamp) flocal[g] = atomicAdd(nlocal, 1);
+        }
+    }
+    unsigned long long todo = __ballot(longm && sub == 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int vv = __shfl(v, src, WAVE), nn = __shfl(n, src, WAVE);
+        const int *L = P.pool + P.inc_off[vv];
+        for (int j = lane; j < nn; j += WAVE) {
+            int g = L[j];
+            if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= stamp) continue;
+            int old = atomicMax(&fstamp[g], stamp);
+            if (old < stamp) flocal[g] = atomicAdd(nlocal, 1);
+        }
     }
 }
 __global__ __launch_bounds__(PB) void k_build_bits(PolyView P, const int *members, int nm, int W, const int *flocal, unsigned long long *bits)
 {
-    int t = blockIdx.x * PB + threadIdx.x;
-    int m = t / LPM, sub = t % LPM;
-    if (m >= nm) return;
-    int v = members[m];
-    const int *L = P.pool + P.inc_off[v];
-    int n = P.inc_len[v];
-    for (int j = sub; j < n; j += LPM) {
-        int id = flocal[L[j]];
-        atomicOr(&bits[(size_t)(id >> 6) * nm + m], 1ull << (id & 63));
+    const int t = blockIdx.x * PB + threadIdx.x, lane = threadIdx.x & 63;
+    const int m = t / LPM, sub = t % LPM;
+    const bool valid = m < nm;
+    int v = -1, n = 0;
+    if (valid) { v = members[m]; n = P.inc_len[v]; }
+    const bool longm = valid && n > LONGN;
+    if (valid && !longm) {
+        const int *L = P.pool + P.inc_off[v];
+        for (int j = sub; j < n; j += LPM) {
+            int id = flocal[L[j]];
+            atomicOr(&bits[(size_t)(id >> 6) * nm + m], 1ull << (id & 63));
+        }
+    }
+    unsigned long long todo = __ballot(longm && sub == 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int vv = __shfl(v, src, WAVE), nn = __shfl(n, src, WAVE), mm = __shfl(m, src, WAVE);
+        const int *L = P.pool + P.inc_off[vv];
+        for (int j = lane; j < nn; j += WAVE) {
+            int id = flocal[L[j]];
+            atomicOr(&bits[(size_t)(id >> 6) * nm + mm], 1ull << (id & 63));
+        }
     }
 }
 __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum)
