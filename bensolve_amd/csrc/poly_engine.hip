@@ -808,6 +808,7 @@ __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned lo
     (void)block_exscan(t, &tot, lds);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
+
 __global__ __launch_bounds__(PB) void k_pair_emit(const int *members, int nm, const PairBlk *blks, const unsigned char *pflag,
                                                    const Tri *bpre, int2 *E, int ebase)
 {
@@ -819,6 +820,451 @@ __global__ __launch_bounds__(PB) void k_pair_emit(const int *members, int nm, co
     Tri ex = block_exscan(t, &tot, lds);
     if (!f) return;
     E[ebase + bpre[blockIdx.x].a + ex.a] = int2{members[pb.i], members[pb.j0 + threadIdx.x]};
+}
+
+
+// =====================================================================================================
+// Single-cut pipeline in five launches (was fourteen): every kernel boundary is ~3-5 us of latency, far
+// more than the work of a cut on a q=5 upper image, so passes that do not depend on each other share a
+// launch (edge blocks first, vertex blocks behind them) and the adjacency prune runs in one workgroup.
+//   k_classify | k_flags2 | k_scan2 -> host | k_emit2 | k2_fused -> host
+// =====================================================================================================
+
+// a ZERO element keeps the facets it shares with a PLUS neighbour (bslv_poly.c:634-652): marks keep[]
+// thousands of edges of one extreme direction mark the same few hundred bytes: the stores to one cache line
+// serialise in L2 (measured ~90 us per cut with an on-plane direction), so look first (L2-coherent load) and
+// store only what is not yet marked
+__device__ __forceinline__ void set_keep(unsigned char *K, int idx)
+{
+    if (!__hip_atomic_load(&K[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) K[idx] = 1;
+}
+__device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed)
+{
+    const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
+    int z = -1, pl = -1;
+    if (ca == 0 && cb == 1) { z = ed.x; pl = ed.y; }
+    else if (ca == 1 && cb == 0) { z = ed.y; pl = ed.x; }
+    if (z < 0) return;
+    const int *A = P.pool + P.inc_off[z], *Bp = P.pool + P.inc_off[pl];
+    unsigned char *K = P.keep + P.inc_off[z];
+    const int na = P.inc_len[z], nb = P.inc_len[pl];
+    if (na <= LCAP && nb <= LCAP) {
+        int RA[LCAP], RB[LCAP];
+        load_list(A, na, RA); load_list(Bp, nb, RB);
+        unsigned m = match_mask(RA, na, RB);
+        while (m) { int a = __ffs((int)m) - 1; m &= m - 1; set_keep(K, a); }
+    } else if (na <= LCAP) {                 // ZERO element short, PLUS neighbour long
+        int RA[LCAP], pos[LCAP];
+        load_list(A, na, RA);
+        unsigned m = match_mask_long(RA, na, Bp, nb, pos);
+        while (m) { int a = __ffs((int)m) - 1; m &= m - 1; set_keep(K, a); }
+    } else if (nb <= LCAP) {                 // ZERO element long (a direction), PLUS neighbour short
+        int RB[LCAP], pos[LCAP];
+        load_list(Bp, nb, RB);
+        unsigned m = match_mask_long(RB, nb, A, na, pos);
+#pragma unroll
+        for (int b2 = 0; b2 < LCAP; b2++) if ((m >> b2) & 1u) set_keep(K, pos[b2]);
+    } else {
+        int i = 0, j = 0;
+        while (i < na && j < nb) {
+            int x = A[i], y = Bp[j];
+            if (x == y) set_keep(K, i);
+            i += (x <= y);
+            j += (y <= x);
+        }
+    }
+}
+
+// flags pass.  Edge blocks: eflag + (survive, cross, new list length) sums, and -- once the cut is known to
+// remove something (counters[0] = #MINUS, final since k_classify) -- the keep marks of ZERO-PLUS edges.
+// Vertex blocks: (is ZERO, 0, old list length + 1): the rebuilt list of an on-plane element is allocated at
+// its upper bound, so its place in the pool does not wait for the keep marks.
+// ne_dev != nullptr: the edge count of the previous cut is still on the device (its adjacent pairs were
+// appended without a host round trip); ne_ub then only sizes the grid.
+__global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne_ub, const int *ne_dev, int nbe, int nv0, const int *counters,
+                                               unsigned char *eflag, Tri *ebsum, Tri *vbsum)
+{
+    __shared__ Tri lds[16];
+    Tri t{0, 0, 0};
+    Tri tot;
+    if ((int)blockIdx.x < nbe) {
+        const int ne = ne_dev ? *ne_dev : ne_ub;
+        const int e = blockIdx.x * PB + threadIdx.x;
+        if (e < ne) {
+            unsigned char f;
+            const int2 ed = E[e];
+            t = edge_triple(P, ed, &f);
+            eflag[e] = f;
+            if (f == 4 && counters[0] > 0) mark_keep(P, ed);
+        }
+        (void)block_exscan(t, &tot, lds);
+        if (threadIdx.x == 0) ebsum[blockIdx.x] = tot;
+    } else {
+        const int b = blockIdx.x - nbe, i = b * PB + threadIdx.x;
+        if (i < nv0 && P.cls[i] == 0) { t.a = 1; t.c = P.inc_len[i] + 1; }
+        (void)block_exscan(t, &tot, lds);
+        if (threadIdx.x == 0) vbsum[b] = tot;
+    }
+}
+// both scans in one launch: workgroup 0 the edge sums (-> totals[0], mail[0] with the classify counters and,
+// in cnt[3], the exact edge count this cut saw), workgroup 1 the vertex sums (-> totals[1])
+__global__ __launch_bounds__(1024) void k_scan2(Tri *ebsum, int nbe, Tri *vbsum, int nbv, Tri *totals, Mail *mail, const int *counters,
+                                                int ne_ub, const int *ne_dev, int seq)
+{
+    __shared__ Tri lds[16];
+    Tri *sums = blockIdx.x == 0 ? ebsum : vbsum;
+    const int nb = blockIdx.x == 0 ? nbe : nbv;
+    Tri carry{0, 0, 0};
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        Tri v = i < nb ? sums[i] : Tri{0, 0, 0};
+        Tri tot;
+        Tri ex = block_exscan(v, &tot, lds);
+        if (i < nb) sums[i] = tri_add(ex, carry);
+        carry = tri_add(carry, tot);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[blockIdx.x] = carry;
+        if (blockIdx.x == 0) {
+            mail->t = carry;
+            for (int k = 0; k < 3; k++) mail->cnt[k] = counters[k];
+            mail->cnt[3] = ne_dev ? *ne_dev : ne_ub;
+            __threadfence_system();
+            mail->seq = seq;
+        }
+    }
+}
+
+// emit pass.  Edge blocks: survivors -> Enew[0..nsurv), one new vertex per crossing edge (coordinates, flags,
+// incidence list, its edge to the PLUS end at Enew[nsurv + crossidx]).  Vertex blocks: MINUS elements leave,
+// ZERO elements get their kept facets + the new one at pool[pool_z + prefix) and become members[0..nzero).
+template <int D>
+__global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, const int2 *E, int ne_ub, const int *ne_dev, int nbe,
+                                              const unsigned char *eflag, const Tri *ebpre, const Tri *vbpre, const Tri *totals,
+                                              int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members)
+{
+    __shared__ Tri lds[16];
+    Tri t{0, 0, 0};
+    Tri tot;
+    if ((int)blockIdx.x < nbe) {
+        const int ne = ne_dev ? *ne_dev : ne_ub;
+        const int e = blockIdx.x * PB + threadIdx.x;
+        unsigned char f = 0;
+        int2 ed{0, 0};
+        if (e < ne) {
+            f = eflag[e]; ed = E[e];
+            if (f == 1 || f == 4) t.a = 1;
+            else if (f >= 2) {
+                t.b = 1;
+                t.c = isect_count_fast(P.pool + P.inc_off[ed.x], P.inc_len[ed.x], P.pool + P.inc_off[ed.y], P.inc_len[ed.y]) + 1;
+            }
+        }
+        Tri ex = block_exscan(t, &tot, lds);
+        if (e >= ne) return;
+        ex = tri_add(ex, ebpre[blockIdx.x]);
+        const int d = D > 0 ? D : P.d;
+        if (f == 1 || f == 4) Enew[ex.a] = ed;
+        else if (f == 2 || f == 3) {
+            const int mi = (f == 2) ? ed.x : ed.y, pl = (f == 2) ? ed.y : ed.x;
+            const int w = nv0 + ex.b;
+            const bool im = P.flag[mi] & F_IDEAL, ip = P.flag[pl] & F_IDEAL;
+            constexpr int DD = D > 0 ? D : MAXD;
+            double xm[DD], xp[DD], base[DD], dirv[DD];
+#pragma unroll
+            for (int k = 0; k < DD; k++) { xm[k] = k < d ? P.X[(size_t)k * P.cap + mi] : 0.0; xp[k] = k < d ? P.X[(size_t)k * P.cap + pl] : 0.0; }
+            double hb = 0.0, hd = 0.0, a2 = hp.h[d];
+            unsigned char nf = F_USED;
+            // new vertex on the edge (bslv_poly.c:597-627); same operation order as oracle/poly_dd.c
+            if (ip && im) {
+                a2 = 0.0; nf |= F_IDEAL;
+#pragma unroll
+                for (int k = 0; k < DD; k++) { base[k] = xm[k]; dirv[k] = xp[k] - xm[k]; }
+            } else if (!ip && !im) {
+#pragma unroll
+                for (int k = 0; k < DD; k++) { base[k] = xp[k]; dirv[k] = xm[k] - xp[k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < DD; k++) { base[k] = ip ? xm[k] : xp[k]; dirv[k] = ip ? xp[k] : xm[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < DD; k++) if (k < d) hd = fma(hp.h[k], dirv[k], hd);
+#pragma unroll
+            for (int k = 0; k < DD; k++) if (k < d) hb = fma(hp.h[k], base[k], hb);
+            const double mu = (a2 - hb) / hd;
+#pragma unroll
+            for (int k = 0; k < DD; k++) if (k < d) P.X[(size_t)k * P.cap + w] = fma(mu, dirv[k], base[k]);
+            P.flag[w] = nf;
+            P.cls[w] = 0;
+            // incidence = inc(minus) & inc(plus) + new facet (bslv_poly.c:634-665)
+            const unsigned off = pool_e + (unsigned)ex.c;
+            int *out = P.pool + off;
+            const int *A = P.pool + P.inc_off[mi], *Bp = P.pool + P.inc_off[pl];
+            int na = P.inc_len[mi], nb = P.inc_len[pl], n = 0;
+            if (na <= LCAP && nb <= LCAP) {
+                int RA[LCAP], RB[LCAP];
+                load_list(A, na, RA); load_list(Bp, nb, RB);
+                const unsigned m = match_mask(RA, na, RB);
+#pragma unroll
+                for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = RA[a];
+            } else if (na <= LCAP || nb <= LCAP) {       // one end is a direction with a long list
+                const bool ashort = na <= nb;
+                int S[LCAP], pos[LCAP];
+                load_list(ashort ? A : Bp, ashort ? na : nb, S);
+                const unsigned m = match_mask_long(S, ashort ? na : nb, ashort ? Bp : A, ashort ? nb : na, pos);
+#pragma unroll
+                for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = S[a];
+            } else {
+                int i = 0, j = 0;
+                while (i < na && j < nb) {
+                    int x = A[i], y = Bp[j];
+                    if (x == y) out[n++] = x;
+                    i += (x <= y);
+                    j += (y <= x);
+                }
+            }
+            out[n++] = facet;
+            P.inc_off[w] = off;
+            P.inc_len[w] = n;
+            Enew[totals[0].a + ex.b] = int2{w, pl};
+        }
+        return;
+    }
+    // ---- vertex blocks ----
+    const int b = blockIdx.x - nbe, i = b * PB + threadIdx.x, lane = threadIdx.x & 63;
+    signed char c = 2;
+    int n = 0;
+    unsigned off_old = 0;
+    if (i < nv0) {
+        c = P.cls[i];
+        if (c == 0) { off_old = P.inc_off[i]; n = P.inc_len[i]; t.a = 1; t.c = n + 1; }
+    }
+    Tri ex = block_exscan(t, &tot, lds);
+    ex = tri_add(ex, vbpre[b]);
+    const unsigned off_new = pool_z + (unsigned)ex.c;
+    const bool longz = (c == 0) && n > LONGN;
+    {   // long lists (extreme directions): ordered compaction by the whole wave (ballot ranks), then the new facet
+        unsigned long long todo = __ballot(longz);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned oo = __shfl(off_old, src, WAVE), on = __shfl(off_new, src, WAVE);
+            const int nn = __shfl(n, src, WAVE), vv = __shfl(i, src, WAVE);
+            int base = 0;
+            for (int j0 = 0; j0 < nn; j0 += WAVE) {
+                const int j = j0 + lane;
+                const bool k = j < nn && P.keep[oo + j];
+                const unsigned long long bm = __ballot(k);
+                if (k) { P.pool[on + base + __popcll(bm & ((1ull << lane) - 1ull))] = P.pool[oo + j]; P.keep[oo + j] = 0; }
+                base += __popcll(bm);
+            }
+            if (lane == 0) { P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; }
+        }
+    }
+    if (i >= nv0) return;
+    if (c == -1) { P.flag[i] &= ~F_USED; return; }
+    if (c != 0) return;
+    members[ex.a] = i;
+    if (longz) return;
+    int m = 0;
+    if (n <= LCAP) {
+        int lst[LCAP];
+        unsigned keptmask = 0;
+        const unsigned char *K = P.keep + off_old;
+        load_list(P.pool + off_old, n, lst);
+#pragma unroll
+        for (int j = 0; j < LCAP; j++) { unsigned k = (j < n) ? K[j] : 0; keptmask |= (k & 1u) << j; }
+#pragma unroll
+        for (int j = 0; j < LCAP; j++) if ((keptmask >> j) & 1u) { P.pool[off_new + m++] = lst[j]; P.keep[off_old + j] = 0; }
+    } else
+        for (int j = 0; j < n; j++)
+            if (P.keep[off_old + j]) { P.pool[off_new + m++] = P.pool[off_old + j]; P.keep[off_old + j] = 0; }
+    P.pool[off_new + m++] = facet;
+    P.inc_off[i] = off_new;
+    P.inc_len[i] = m;
+}
+
+// ---- K2 in ONE workgroup: the adjacency prune over the members of the new facet (bslv_poly.c:482-540) ----
+// Facets that occur in fewer than two member lists can never be mutual, so only the others get a local id:
+// the bit matrix then fits in LDS even though the extreme directions carry lists of thousands of facets.
+//   P1 mark facets seen twice   P2 local ids   P3 bit matrix (LDS)   P4 candidate pairs (>= d-1 mutual facets)
+//   P5 superset sweeps, one wave per candidate   P6 ordered emission at E[ebase..)
+// fstamp[g] in {S0 seen once, S0+1 seen twice, S0+2 id assigned}, S0 = 4 * cut sequence number (monotone, no reset).
+// Falls back (mail t.b = 1) when the bit matrix does not fit; the host then runs the multi-kernel path.
+constexpr int K2T = 1024, K2_MAXNM = 512, K2_MAXLONG = 64;
+__device__ __forceinline__ void pair_decode(long long p, int nm, int &i, int &j)
+{
+    const double b2 = 2.0 * nm - 1.0;
+    int ii = (int)((b2 - sqrt(b2 * b2 - 8.0 * (double)p)) * 0.5);
+    ii = ii < 0 ? 0 : (ii > nm - 2 ? nm - 2 : ii);
+    while ((long long)ii * (2 * nm - ii - 1) / 2 > p) ii--;
+    while ((long long)(ii + 1) * (2 * nm - ii - 2) / 2 <= p) ii++;
+    i = ii;
+    j = ii + 1 + (int)(p - (long long)ii * (2 * nm - ii - 1) / 2);
+}
+template <class F>
+__device__ __forceinline__ void k2_for_entries(const int *pool, int nm, const unsigned *s_off, const int *s_len, const unsigned char *s_islong,
+                                               const int *s_long, int nlong, F f)
+{
+    for (int m = threadIdx.x / LPM; m < nm; m += K2T / LPM) {
+        if (s_islong[m]) continue;
+        const int *L = pool + s_off[m];
+        const int n = s_len[m];
+        for (int j = threadIdx.x % LPM; j < n; j += LPM) f(m, L[j]);
+    }
+    for (int k = 0; k < nlong; k++) {
+        const int m = s_long[k];
+        const int *L = pool + s_off[m];
+        const int n = s_len[m];
+        for (int j = threadIdx.x; j < n; j += K2T) f(m, L[j]);
+    }
+}
+// P4+P5 of k2_fused, one pair per thread: a candidate (>= d-1 mutual facets, edge_test bslv_poly.c:482-485) is
+// adjacent unless another member lies on all its mutual facets, i.e. unless the intersection of the member sets
+// (rows) of its mutual facets holds more than the pair itself: |M| short independent row reads instead of a
+// sweep over all members (the sweep, one dependent LDS read per member, cost 25 us per cut).
+// NWC = compile-time bound of the row length in words, so the accumulator stays in registers.
+template <int NWC>
+__device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const unsigned long long *bits, const unsigned long long *rows, unsigned *adj_bits)
+{
+    const int npairs = nm * (nm - 1) / 2;
+    if ((int)threadIdx.x >= npairs) return;
+    int i, j;
+    pair_decode(threadIdx.x, nm, i, j);
+    for (int p = threadIdx.x; p < npairs; p += K2T) {
+        int nmut = 0;
+        for (int w = 0; w < W; w++) nmut += __popcll(bits[w * nm + i] & bits[w * nm + j]);
+        bool adj = d == 1 || nmut >= d - 1;
+        if (adj && d > 1) {
+            unsigned long long acc[NWC];
+#pragma unroll
+            for (int k = 0; k < NWC; k++) acc[k] = ~0ull;
+            for (int w = 0; w < W; w++) {
+                unsigned long long M = bits[w * nm + i] & bits[w * nm + j];
+                while (M) {
+                    const int f = (w << 6) + __ffsll((long long)M) - 1;
+                    M &= M - 1;
+#pragma unroll
+                    for (int k = 0; k < NWC; k++) acc[k] &= (NWC == 1 || k < NW) ? rows[f * NW + k] : 0ull;
+                }
+            }
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < NWC; k++) cnt += __popcll(acc[k]);
+            adj = cnt == 2;                       // i and j themselves lie on all their mutual facets
+        }
+        if (adj) atomicOr(&adj_bits[p >> 5], 1u << (p & 31));
+        // step K2T pairs ahead in the lexicographic order
+        j += K2T;
+        while (j >= nm && i < nm - 1) { j -= nm - 2 - i; i++; }
+    }
+}
+__global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nzero, int nv0, int ncross, int S0, int *fstamp, int *flocal,
+                                                int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg)
+{
+    extern __shared__ unsigned long long k2_dyn[];
+    unsigned long long t_prev = dbg ? wall_clock64() : 0ull;
+#define K2_PHASE(k) do { if (dbg && threadIdx.x == 0) { unsigned long long t_now = wall_clock64(); dbg[k] += t_now - t_prev; t_prev = t_now; } } while (0)
+    __shared__ Tri lds[16];
+    __shared__ unsigned s_off[K2_MAXNM];
+    __shared__ int s_len[K2_MAXNM], s_mem[K2_MAXNM], s_long[K2_MAXLONG];
+    __shared__ unsigned char s_islong[K2_MAXNM];
+    __shared__ int s_nlong, s_nloc, s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nm = nzero + ncross, d = P.d;
+    const int S1 = S0 + 1, S2 = S0 + 2;
+    const long long npairs = (long long)nm * (nm - 1) / 2;
+    const int nadjw = (int)((npairs + 31) / 32);
+    unsigned *adj_bits = (unsigned *)k2_dyn;
+    unsigned long long *bits = k2_dyn + (nadjw + 1) / 2;
+    const long long bits_cap = (long long)lds_words - (nadjw + 1) / 2;
+    // P0: members (ZERO elements from k_emit2, then the new vertices), their lists
+    for (int m = tid; m < nm; m += K2T) {
+        int v;
+        if (m < nzero) v = members[m]; else { v = nv0 + (m - nzero); members[m] = v; }
+        s_mem[m] = v; s_off[m] = P.inc_off[v]; s_len[m] = P.inc_len[v]; s_islong[m] = 0;
+    }
+    for (int w = tid; w < nadjw; w += K2T) adj_bits[w] = 0u;
+    if (tid == 0) { s_nlong = 0; s_nloc = 0; s_carry = 0; }
+    __syncthreads();
+    for (int m = tid; m < nm; m += K2T)
+        if (s_len[m] > LONGN) { int k = atomicAdd(&s_nlong, 1); if (k < K2_MAXLONG) { s_long[k] = m; s_islong[m] = 1; } }
+    __syncthreads();
+    const int nlong = s_nlong < K2_MAXLONG ? s_nlong : K2_MAXLONG;
+    K2_PHASE(0);
+    // P1
+    k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) {
+        if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= S1) return;
+        const int old = atomicMax(&fstamp[g], S0);
+        if (old == S0) atomicMax(&fstamp[g], S1);
+    });
+    __threadfence_block();
+    __syncthreads();
+    K2_PHASE(1);
+    // P2
+    k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) {
+        if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S1) return;
+        const int old = atomicMax(&fstamp[g], S2);
+        if (old == S1) __hip_atomic_store(&flocal[g], atomicAdd(&s_nloc, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    __threadfence_block();
+    __syncthreads();
+    K2_PHASE(2);
+    const int W = (s_nloc + 63) >> 6, NW = (nm + 63) >> 6;
+    unsigned long long *rows = bits + W * nm;        // rows[f * NW + k]: members on local facet f
+    if ((long long)W * nm + (long long)W * 64 * NW > bits_cap) {             // uniform: every thread sees the same s_nloc
+        if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; mail->t = r; __threadfence_system(); mail->seq = seq; }
+        return;
+    }
+    for (int w = tid; w < W * nm + W * 64 * NW; w += K2T) bits[w] = 0ull;
+    __syncthreads();
+    // P3
+    k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int m, int g) {
+        if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S2) return;
+        const int id = __hip_atomic_load(&flocal[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicOr(&bits[(id >> 6) * nm + m], 1ull << (id & 63));
+        atomicOr(&rows[id * NW + (m >> 6)], 1ull << (m & 63));
+    });
+    __syncthreads();
+    K2_PHASE(3);
+    // P4+P5 (k2_pairs)
+    if (NW <= 1) k2_pairs<1>(nm, d, W, NW, bits, rows, adj_bits);
+    else if (NW <= 2) k2_pairs<2>(nm, d, W, NW, bits, rows, adj_bits);
+    else if (NW <= 4) k2_pairs<4>(nm, d, W, NW, bits, rows, adj_bits);
+    else k2_pairs<K2_MAXNM / 64>(nm, d, W, NW, bits, rows, adj_bits);
+    __syncthreads();
+    K2_PHASE(4);
+    K2_PHASE(5);
+    // P6: adjacent pairs in lexicographic order; the 32 pairs of a bitmap word are consecutive, so (i, j) is
+    // decoded once per word and stepped
+    for (int w0 = 0; w0 < nadjw; w0 += K2T) {
+        const int ww = w0 + tid;
+        unsigned word = ww < nadjw ? adj_bits[ww] : 0u;
+        Tri t{(int)__popc(word), 0, 0};
+        Tri tot;
+        Tri ex = block_exscan(t, &tot, lds);
+        int at = ebase + s_carry + ex.a;
+        if (word) {
+            int i, j;
+            pair_decode((long long)ww * 32, nm, i, j);
+            for (int bbit = 0; bbit < 32; bbit++) {
+                if ((word >> bbit) & 1u) E[at++] = int2{s_mem[i], s_mem[j]};
+                if (++j == nm) { i++; j = i + 1; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += tot.a;
+        __syncthreads();
+    }
+    K2_PHASE(6);
+    if (tid == 0) {
+        if (dbg) { dbg[7] += 1; dbg[8] += (unsigned long long)W; dbg[9] += (unsigned long long)s_nloc; }
+        Tri r{s_carry, 0, 0};
+        totals[0] = r;
+        if (ne_dev) *ne_dev = ebase + s_carry;
+        mail->t = r;
+        __threadfence_system();
+        mail->seq = seq;
+    }
 }
 
 // unprocessed = used && !sltn (bslv_poly.c:214-216): triple (flag, 0, 0)
@@ -983,6 +1429,13 @@ struct bslv_poly {
     unsigned long long *bits = nullptr; size_t bitscap = 0;                     // local incidence bit matrix
     int mailseq = 0;
     long cutseq = 0;
+    size_t k2_lds = 0;                // dynamic LDS bytes granted to k2_fused
+    int *ne_dev = nullptr;            // edge count as the device knows it (written by k2_fused)
+    bool pend_k2 = false;             // a k2_fused is in flight: ne is an upper bound
+    int pend_seq = 0, pend_ebase = 0, pend_nm = 0, pend_stamp = 0; long long pend_len_ub = 0;
+    int pre_f = -1, pre_slot = 0, pre_nv = 0;   // halfspace already classified (queued behind the previous cut's k_emit2)
+    unsigned long long *k2dbg = nullptr;   // BSLV_K2_DEBUG=1: per-phase clock sums of k2_fused (100 MHz ticks), printed at destroy
+    FILE *cutlog = nullptr;           // BSLV_CUT_LOG=<file>: one line per cut (nv ne nminus nzero zero_ub nsurv ncross newlen), profiling aid
     PairBlk *blks = nullptr; int blkcap = 0;
     unsigned char *pflag = nullptr; size_t pflagcap = 0;
     // dual side (host)
@@ -1156,9 +1609,79 @@ static int wait_mail(bslv_poly *h, int slot, int seq)
     return 0;
 }
 
-// one cut on the device; *rc = 0 cut applied, 1 redundant.  Two host round trips per cut:
-//   A: classify counters + edge totals   B: on-plane totals + adjacent-pair total
-static int do_cut(bslv_poly *h, int f, int *rc_out)
+// the multi-kernel adjacency prune (facets too large for k2_fused, or whose bit matrix does not fit in LDS);
+// members[0..nm) complete.  Appends the adjacent pairs at E[ecur][h->ne..) and advances h->ne.
+// stamp: fstamp value of this prune, above every state k2_fused may have left for the same cut.
+static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
+{
+    hipStream_t s = h->stream;
+    int rc;
+    const long long nbp = pair_G(nm - 1);
+    if (nbp > 0x7FFFFFF0ll) { set_error("new facet has too many elements (%d) for one pair launch", nm); return BSLV_E_CAPACITY; }
+    if ((size_t)nbp * PB > h->pflagcap) { size_t nc = std::max((size_t)nbp * PB, h->pflagcap * 2); if ((rc = grow(&h->pflag, 0, nc, s))) return rc; h->pflagcap = nc; }
+    if ((rc = ensure_bsum(h, (int)nbp + 1))) return rc;
+    // local incidence bit matrix: at most one local id per list entry of the members
+    const int nranks = (int)h->facet_of_rank.size();
+    const int W = (int)((std::min<long long>(len_ub, nranks) + 63) / 64);
+    if ((size_t)W * nm > h->bitscap) { size_t nc = std::max((size_t)W * nm, h->bitscap * 2); if ((rc = grow(&h->bits, 0, nc, s))) return rc; h->bitscap = nc; }
+    const size_t lds_bits = (size_t)W * 5 * sizeof(unsigned long long);
+    if (lds_bits <= 48 * 1024) {
+        HIP_TRY(hipMemsetAsync(h->nlocal, 0, sizeof(int), s));
+        const int nbm = (nm * LPM + PB - 1) / PB;
+        hipLaunchKernelGGL(k_local_ids, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, stamp, h->fstamp, h->flocal, h->nlocal, h->bits);
+        hipLaunchKernelGGL(k_build_bits, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, h->flocal, h->bits);
+        hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, h->d, h->bits, nm, W, h->pflag, h->bsum);
+    } else      // enormous local facet sets: sorted-list version
+        hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)nbp), dim3(PB), 0, s, h->P, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum);
+    const int seq = ++h->mailseq;
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, (int)nbp, h->totals + 2, h->mail_d + 2, (const int *)nullptr, seq);
+    HIP_TRY(hipGetLastError());
+    if ((rc = wait_mail(h, 2, seq))) return rc;
+    const Tri tp = h->mail_h[2].t;
+    if (tp.a > 0) {
+        if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
+        hipLaunchKernelGGL(k_pair_emit, dim3((unsigned)nbp), dim3(PB), 0, s, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum,
+                           h->E[h->ecur], h->ne);
+        HIP_TRY(hipGetLastError());
+        h->ne += tp.a;
+    }
+    return 0;
+}
+
+// waits for the adjacency prune still in flight (k2_fused of the previous cut) and books its edges; when the
+// kernel reported that its bit matrix did not fit, runs the multi-kernel prune instead.  *redo (may be NULL) is
+// set in that case: whatever was launched behind the failed kernel saw an incomplete edge list.
+static int settle_k2(bslv_poly *h, bool *redo = nullptr)
+{
+    if (redo) *redo = false;
+    if (!h->pend_k2) return 0;
+    int rc;
+    if ((rc = wait_mail(h, 2, h->pend_seq))) return rc;
+    h->pend_k2 = false;
+    const Tri tp = h->mail_h[2].t;
+    if (tp.b) {
+        h->ne = h->pend_ebase;
+        if (redo) *redo = true;
+        return k2_multi(h, h->pend_nm, h->pend_len_ub, h->pend_stamp);
+    }
+    h->ne = h->pend_ebase + tp.a;
+    return 0;
+}
+static int next_counter_slot(bslv_poly *h)
+{
+    const int cslot = (int)(h->cutseq % CRING);
+    if (cslot == 0 && h->cutseq > 0 && hipMemsetAsync(h->counters, 0, CRING * 4 * sizeof(int), h->stream) != hipSuccess) return -1;
+    h->cutseq++;
+    return cslot;
+}
+
+// one cut on the device; *rc = 0 cut applied, 1 redundant.  Five launches and ONE host round trip:
+//   [k_classify] k_flags2 k_scan2 -> host (redundant? capacities) -> k_emit2 [k_classify of next_f] k2_fused
+// The adjacency prune is left in flight: its pairs land behind the edges of this cut on the device, the next
+// cut reads the edge count from there (ne_dev) and the host books it at its next wait (settle_k2).  The
+// classification of the next halfspace is queued between k_emit2 and k2_fused, where its launch latency hides.
+// Callers finish a sequence of cuts with settle_k2().
+static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
 {
     const int d = h->d, nv0 = h->nv;
     hipStream_t s = h->stream;
@@ -1166,23 +1689,42 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
     memset(&hp, 0, sizeof(hp));
     memcpy(hp.h, &h->hp[(size_t)f * (d + 1)], (d + 1) * sizeof(double));
     int rc;
-    const int cslot = (int)(h->cutseq % CRING);
-    if (cslot == 0 && h->cutseq > 0) HIP_TRY(hipMemsetAsync(h->counters, 0, CRING * 4 * sizeof(int), s));
-    h->cutseq++;
-    int *counters = h->counters + 4 * cslot;
-    const int ne0 = h->ne, nbe = std::max(1, (ne0 + PB - 1) / PB), nbv = (nv0 + PB - 1) / PB;
-    if ((rc = ensure_bsum(h, std::max(nbe, nbv) + 1))) return rc;
-    const int2 *Eold = h->E[h->ecur];
-    int2 *Enew = h->E[1 - h->ecur];
-    // ---- round A: K1 + edge flags + scan -> host ----
-    hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters);
-    hipLaunchKernelGGL(k_edge_flags, dim3(nbe), dim3(PB), 0, s, h->P, Eold, ne0, h->eflag, h->bsum);
-    const int seqA = ++h->mailseq;
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, nbe, h->totals + 0, h->mail_d + 0, counters, seqA);
-    HIP_TRY(hipGetLastError());
-    if ((rc = wait_mail(h, 0, seqA))) return rc;
-    const int nminus = h->mail_h[0].cnt[0], nzero = h->mail_h[0].cnt[1], zero_ub = h->mail_h[0].cnt[2];
-    const Tri te = h->mail_h[0].t;
+    bool classified = h->pre_f == f && h->pre_nv == nv0;
+    int cslot = classified ? h->pre_slot : next_counter_slot(h);
+    h->pre_f = -1;
+    if (cslot < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
+    const int nbv = (nv0 + PB - 1) / PB;
+    int nbe, nminus, nzero, zero_ub;
+    Tri te;
+    Tri *ebsum, *vbsum;
+    for (;;) {
+        int *counters = h->counters + 4 * cslot;
+        const int ne_ub = h->ne;                   // exact unless a prune is in flight
+        const int *ne_dev = h->pend_k2 ? h->ne_dev : nullptr;
+        nbe = std::max(1, (ne_ub + PB - 1) / PB);
+        if ((rc = ensure_bsum(h, nbe + nbv + 2))) return rc;
+        ebsum = h->bsum; vbsum = h->bsum + nbe + 1;
+        // room for the survivors + crossing edges (<= ne) and every pair of a small facet (k2_fused emits in place)
+        if ((rc = ensure_ecap(h, ne_ub + K2_MAXNM * (K2_MAXNM - 1) / 2 + 1))) return rc;
+        // ---- round A ----
+        if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters);
+        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, ebsum, vbsum);
+        const int seqA = ++h->mailseq;
+        hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA);
+        HIP_TRY(hipGetLastError());
+        if ((rc = wait_mail(h, 0, seqA))) return rc;
+        bool redo;
+        if ((rc = settle_k2(h, &redo))) return rc;
+        if (!redo) break;
+        // the previous prune was redone by the multi-kernel path: classify and flag again on the complete edge list
+        classified = false;
+        if ((cslot = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
+    }
+    nminus = h->mail_h[0].cnt[0]; nzero = h->mail_h[0].cnt[1]; zero_ub = h->mail_h[0].cnt[2];
+    te = h->mail_h[0].t;
+    const int ne0 = h->ne;
+    if (h->mail_h[0].cnt[3] != ne0) { set_error("internal: edge count on the device %d, on the host %d", h->mail_h[0].cnt[3], ne0); return BSLV_E_STATE; }
+    if (h->cutlog) fprintf(h->cutlog, "%d %d %d %d %d %d %d %d\n", nv0, ne0, nminus, nzero, zero_ub, te.a, te.b, te.c);
     if (nminus == 0) { h->fapplied[f] = 0; *rc_out = 1; return 0; }
     const int rank = (int)h->facet_of_rank.size();
     h->facet_of_rank.push_back(f);
@@ -1190,31 +1732,35 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
     if ((rc = ensure_vcap(h, nv0 + ncross))) return rc;
     if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
     const unsigned pool_e = h->poolused, pool_z = h->poolused + (unsigned)te.c;
-    // ---- round B: edge emit, on-plane rebuild, pair flags + scan -> host ----
+    const int2 *Eold = h->E[h->ecur];
+    int2 *Enew = h->E[1 - h->ecur];
+    // ---- round B ----
     switch (d) {
-#define CASE(D) case D: hipLaunchKernelGGL(k_edge_emit<D>, dim3(nbe), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, h->eflag, h->bsum, h->totals + 0, Enew, nv0, pool_e); break;
+#define CASE(D) case D: hipLaunchKernelGGL(k_emit2<D>, dim3(nbe + nbv), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, (const int *)nullptr, nbe, h->eflag, ebsum, vbsum, h->totals + 0, Enew, nv0, pool_e, pool_z, h->members); break;
         CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
-    default: hipLaunchKernelGGL(k_edge_emit<0>, dim3(nbe), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, h->eflag, h->bsum, h->totals + 0, Enew, nv0, pool_e); break;
+    default: hipLaunchKernelGGL(k_emit2<0>, dim3(nbe + nbv), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, (const int *)nullptr, nbe, h->eflag, ebsum, vbsum, h->totals + 0, Enew, nv0, pool_e, pool_z, h->members); break;
     }
-    hipLaunchKernelGGL(k_vert_flags, dim3(nbv), dim3(PB), 0, s, h->P, nv0, h->bsum);
-    const int seqB1 = ++h->mailseq;
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, nbv, h->totals + 1, h->mail_d + 1, (const int *)nullptr, seqB1);
-    hipLaunchKernelGGL(k_vert_emit, dim3(nbv), dim3(PB), 0, s, h->P, rank, nv0, h->bsum, h->members, pool_z);
-    if (ncross > 0) hipLaunchKernelGGL(k_iota_members, dim3((ncross + 255) / 256), dim3(256), 0, s, h->members, nzero, nv0, ncross);
+    h->poolused += (unsigned)te.c + (unsigned)zero_ub;
+    h->nv = nv0 + ncross;
+    h->ne = nsurv + ncross;
+    h->ecur = 1 - h->ecur;
+    h->new_vertices += ncross;
+    const int my_seq = (int)h->cutseq;           // fstamp states of this cut: 4*my_seq .. 4*my_seq+3
+    if (next_f >= 0) {
+        // classify the next halfspace now (the new vertices exist once k_emit2 has run; k2 does not read classes)
+        Hp hn;
+        memset(&hn, 0, sizeof(hn));
+        memcpy(hn.h, &h->hp[(size_t)next_f * (d + 1)], (d + 1) * sizeof(double));
+        const int ns = next_counter_slot(h);
+        if (ns < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
+        hipLaunchKernelGGL(k_classify, dim3((h->nv + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + 4 * ns);
+        h->pre_f = next_f; h->pre_slot = ns; h->pre_nv = h->nv;
+    }
     const int nm = nzero + ncross;
-    long long nbp = 0;
-    int seqB2 = 0;
     if (nm >= 2) {
-        nbp = pair_G(nm - 1);
-        if (nbp > 0x7FFFFFF0ll) { set_error("new facet has too many elements (%d) for one pair launch", nm); return BSLV_E_CAPACITY; }
         h->pair_tests += (long)nm * (nm - 1) / 2;
-        if ((size_t)nbp * PB > h->pflagcap) { size_t nc = std::max((size_t)nbp * PB, h->pflagcap * 2); if ((rc = grow(&h->pflag, 0, nc, s))) return rc; h->pflagcap = nc; }
-        if ((rc = ensure_bsum(h, (int)nbp + 1))) return rc;
-        // local incidence bit matrix: at most one local id per list entry of the members
-        const long long len_ub = (long long)te.c + zero_ub;
         const int nranks = (int)h->facet_of_rank.size();
-        const int W = (int)((std::min<long long>(len_ub, nranks) + 63) / 64);
         if (nranks > h->fcap) {
             int nc = std::max(nranks + 1024, h->fcap * 2);
             if ((rc = grow(&h->fstamp, (size_t)h->fcap, (size_t)nc, s, true))) return rc;
@@ -1222,41 +1768,20 @@ static int do_cut(bslv_poly *h, int f, int *rc_out)
             if (!h->nlocal && (rc = grow(&h->nlocal, 0, 4, s, true))) return rc;
             h->fcap = nc;
         }
-        if ((size_t)W * nm > h->bitscap) { size_t nc = std::max((size_t)W * nm, h->bitscap * 2); if ((rc = grow(&h->bits, 0, nc, s))) return rc; h->bitscap = nc; }
-        const size_t lds_bits = (size_t)W * 5 * sizeof(unsigned long long);
-        if (lds_bits <= 48 * 1024) {
-            HIP_TRY(hipMemsetAsync(h->nlocal, 0, sizeof(int), s));
-            const int nbm = (nm * LPM + PB - 1) / PB;
-            hipLaunchKernelGGL(k_local_ids, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, (int)h->cutseq, h->fstamp, h->flocal, h->nlocal, h->bits);
-            hipLaunchKernelGGL(k_build_bits, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, h->flocal, h->bits);
-            hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, d, h->bits, nm, W, h->pflag, h->bsum);
-        } else      // enormous local facet sets: sorted-list version
-            hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)nbp), dim3(PB), 0, s, h->P, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum);
-        seqB2 = ++h->mailseq;
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, (int)nbp, h->totals + 2, h->mail_d + 2, (const int *)nullptr, seqB2);
-    }
-    HIP_TRY(hipGetLastError());
-    if ((rc = wait_mail(h, 1, seqB1))) return rc;
-    const Tri tz = h->mail_h[1].t;
-    if (tz.a != nzero) { set_error("internal: ZERO count mismatch %d vs %d", tz.a, nzero); return BSLV_E_STATE; }
-    h->poolused += (unsigned)te.c + (unsigned)tz.c;
-    h->nv = nv0 + ncross;
-    h->ne = nsurv + ncross;
-    h->ecur = 1 - h->ecur;
-    h->new_vertices += ncross;
-    if (nm >= 2) {
-        if ((rc = wait_mail(h, 2, seqB2))) return rc;
-        const Tri tp = h->mail_h[2].t;
-        if (tp.a > 0) {
-            if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
-            hipLaunchKernelGGL(k_pair_emit, dim3((unsigned)nbp), dim3(PB), 0, s, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum,
-                               h->E[h->ecur], h->ne);
+        const long long len_ub = (long long)te.c + zero_ub;
+        if (nm <= K2_MAXNM) {
+            const int seqB = ++h->mailseq;
+            hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, 4 * my_seq, h->fstamp, h->flocal,
+                               (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + 2, seqB, h->k2dbg);
             HIP_TRY(hipGetLastError());
-            h->ne += tp.a;
+            h->pend_k2 = true; h->pend_seq = seqB; h->pend_ebase = h->ne; h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_stamp = 4 * my_seq + 3;
+            h->ne += (int)((long long)nm * (nm - 1) / 2);          // upper bound until settle_k2
+        } else {
+            if (ncross > 0) hipLaunchKernelGGL(k_iota_members, dim3((ncross + 255) / 256), dim3(256), 0, s, h->members, nzero, nv0, ncross);
+            if ((rc = k2_multi(h, nm, len_ub, 4 * my_seq + 3))) return rc;
         }
     }
-    // head-room for the next cut: every edge may cross
-    if ((rc = ensure_ecap(h, h->ne + 1))) return rc;
+    HIP_TRY(hipGetLastError());
     h->cuts_applied++;
     *rc_out = 0;
     return 0;
@@ -1335,7 +1860,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     h->P.d = dim;
     auto fail = [&](int code) { bslv_poly_destroy(h); return code; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
-    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * 4 * sizeof(int)) != hipSuccess ||
+    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->mail_h, 4 * sizeof(Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&h->mail_d, h->mail_h, 0) != hipSuccess ||
@@ -1343,6 +1868,14 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
         set_error("allocation of scan scratch failed");
         return fail(BSLV_E_NOMEM);
     }
+    // k2_fused keeps the local incidence bit matrix in LDS: ask for most of the CU's 160 KB, settle for 48 KB
+    h->k2_lds = 128 * 1024;
+    if (hipFuncSetAttribute((const void *)k2_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess) {
+        (void)hipGetLastError();
+        h->k2_lds = 48 * 1024;
+    }
+    if (const char *cl = getenv("BSLV_CUT_LOG")) h->cutlog = fopen(cl, "w");
+    if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
     // dual slot 0: "facet at infinity", ideal point (0,..,0,-1)  (bslv_poly.c:83-92)
     std::vector<double> z(dim, 0.0);
@@ -1355,9 +1888,17 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
 void bslv_poly_destroy(bslv_poly *h)
 {
     if (!h) return;
+    if (h->cutlog) fclose(h->cutlog);
+    if (h->k2dbg) {
+        unsigned long long t[16];
+        if (hipMemcpy(t, h->k2dbg, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess && t[7])
+            fprintf(stderr, "k2_fused phases (us/launch over %llu launches): P0 %.2f P1 %.2f P2 %.2f P3 %.2f P4 %.2f P5 %.2f P6 %.2f | W %.1f nloc %.0f\n", t[7],
+                    t[0] * 0.01 / t[7], t[1] * 0.01 / t[7], t[2] * 0.01 / t[7], t[3] * 0.01 / t[7], t[4] * 0.01 / t[7], t[5] * 0.01 / t[7], t[6] * 0.01 / t[7], (double)t[8] / t[7], (double)t[9] / t[7]);
+        (void)hipFree(h->k2dbg);
+    }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
-    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
@@ -1381,7 +1922,8 @@ int bslv_poly_add(bslv_poly *h, const double *val, int ideal, int *rc_out)
     if (!h || !val || !rc_out) { set_error("bslv_poly_add: bad argument"); return BSLV_E_ARG; }
     int f = new_dual(h, val, ideal);
     if (!h->initialised) { h->queue.push_back(f); *rc_out = 0; return 0; }
-    return do_cut(h, f, rc_out);
+    int rc = do_cut(h, f, rc_out);
+    return rc ? rc : settle_k2(h);
 }
 
 int bslv_poly_init(bslv_poly *h, int *rc_out)
@@ -1484,13 +2026,16 @@ int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal,
             for (int k = 0; k < nb_; k++) anym[b0 + k] = (bits[k >> 5] >> (k & 31)) & 1u;
         }
     }
+    std::vector<int> todo;
     for (int b = 0; b < B; b++) {
-        if (!anym[b]) { h->fapplied[fids[b]] = 0; rc_out[b] = 1; continue; }
-        int r, rc = do_cut(h, fids[b], &r);
-        if (rc) return rc;
-        rc_out[b] = r;
+        if (!anym[b]) { h->fapplied[fids[b]] = 0; rc_out[b] = 1; } else todo.push_back(b);
     }
-    return 0;
+    for (size_t k = 0; k < todo.size(); k++) {
+        int r, rc = do_cut(h, fids[todo[k]], &r, k + 1 < todo.size() ? fids[todo[k + 1]] : -1);
+        if (rc) return rc;
+        rc_out[todo[k]] = r;
+    }
+    return settle_k2(h);
 }
 
 // Stand-alone batched incidence kernel for tests and the roofline measurement: classes of the
