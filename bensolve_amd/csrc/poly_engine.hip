@@ -24,6 +24,9 @@ constexpr double POLY_EPS = 1e-9;      // bslv_poly.h:47
 constexpr int PB = 256;                // threads per workgroup in the poly kernels
 constexpr unsigned char F_USED = 1, F_IDEAL = 2, F_SLTN = 4;
 constexpr int CRING = 1024;            // ring of per-cut classify counters
+constexpr int LCAP = 16;
+constexpr int LONGN = 64;      // lists longer than this are processed by a whole wave
+constexpr int ZMAX = 8;        // on-plane elements with long lists that get a facet-stamp row per cut (see ZMarks)
 
 struct Hp { double h[MAXD + 1]; };
 struct Tri { int a, b, c; };
@@ -106,7 +109,24 @@ __device__ __forceinline__ signed char classify_one(const PolyView &P, const Hp 
     return (s > a + POLY_EPS) ? 1 : (s > a - POLY_EPS ? 0 : -1);
 }
 // counters[0] = #MINUS, counters[1] = #ZERO
-__global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters)
+// Keep marks of on-plane elements with LONG incidence lists (the extreme directions of an upper image: hundreds
+// to thousands of facets, and a thousand edges each).  Marking "facet shared with a PLUS neighbour" per edge in
+// the element's own keep[] bytes sends thousands of requests to the same few cache lines, which the L2 serves
+// one at a time (measured 40-100 us per cut).  Instead each such element z gets a row of facet stamps:
+// an edge (z, p) stamps row[g] for every facet g of its PLUS end p -- spread over all facets, no searching --
+// and z keeps the facets of its list whose stamp is current.  Same rule as bslv_poly.c:634-652.
+struct ZMarks {
+    const int *zlist;      // up to ZMAX long on-plane elements of this cut (k_classify), count in counters[3]
+    int *rows;             // ZMAX x stride stamps
+    int stride, stamp;
+};
+__device__ __forceinline__ int zmarks_find(const ZMarks &Z, const int *counters, int v)
+{
+    const int nz = counters[3] < ZMAX ? counters[3] : ZMAX;
+    for (int k = 0; k < nz; k++) if (Z.zlist[k] == v) return k;
+    return -1;
+}
+__global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters, int *zlist)
 {
     int i = blockIdx.x * PB + threadIdx.x;
     int isminus = 0, iszero = 0, zlen = 0;
@@ -114,7 +134,10 @@ __global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int 
         unsigned char fl = P.flag[i];
         signed char c = 2;
         if (fl & F_USED) { c = classify_one(P, hp, i, fl); isminus = c < 0; iszero = c == 0; }
-        if (iszero) zlen = P.inc_len[i] + 1;       // upper bound of its rebuilt incidence list
+        if (iszero) {
+            zlen = P.inc_len[i] + 1;               // upper bound of its rebuilt incidence list
+            if (zlen - 1 > LONGN) { const int k = atomicAdd(&counters[3], 1); if (k < ZMAX) zlist[k] = i; }
+        }
         P.cls[i] = c;
     }
     unsigned long long bm = __ballot(isminus), bz = __ballot(iszero);
@@ -266,8 +289,6 @@ __device__ __forceinline__ int isect3_count(const int *a, int na, const int *b, 
 // Short lists (the common case: a vertex of a simple polytope lies on d facets) are fetched with 16
 // independent predicated loads -- ONE memory latency instead of a dependent chain of loads through the
 // merge loop -- and intersected in registers.  Longer lists take the merge loop.
-constexpr int LCAP = 16;
-constexpr int LONGN = 64;      // lists longer than this are processed by a whole wave
 __device__ __forceinline__ void load_list(const int *p, int n, int (&out)[LCAP])
 {
 #pragma unroll
@@ -838,7 +859,7 @@ __device__ __forceinline__ void set_keep(unsigned char *K, int idx)
 {
     if (!__hip_atomic_load(&K[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) K[idx] = 1;
 }
-__device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed)
+__device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed, const ZMarks &Z, const int *counters)
 {
     const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
     int z = -1, pl = -1;
@@ -848,6 +869,20 @@ __device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed)
     const int *A = P.pool + P.inc_off[z], *Bp = P.pool + P.inc_off[pl];
     unsigned char *K = P.keep + P.inc_off[z];
     const int na = P.inc_len[z], nb = P.inc_len[pl];
+    if (na > LONGN) {
+        const int zid = zmarks_find(Z, counters, z);
+        if (zid >= 0) {                          // stamp the facets of the PLUS end in z's row
+            int *row = Z.rows + (size_t)zid * Z.stride;
+            if (nb <= LCAP) {
+                int RB[LCAP];
+                load_list(Bp, nb, RB);
+#pragma unroll
+                for (int b2 = 0; b2 < LCAP; b2++) if (b2 < nb) row[RB[b2]] = Z.stamp;
+            } else
+                for (int b2 = 0; b2 < nb; b2++) row[Bp[b2]] = Z.stamp;
+            return;
+        }
+    }
     if (na <= LCAP && nb <= LCAP) {
         int RA[LCAP], RB[LCAP];
         load_list(A, na, RA); load_list(Bp, nb, RB);
@@ -882,20 +917,33 @@ __device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed)
 // ne_dev != nullptr: the edge count of the previous cut is still on the device (its adjacent pairs were
 // appended without a host round trip); ne_ub then only sizes the grid.
 __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne_ub, const int *ne_dev, int nbe, int nv0, const int *counters,
-                                               unsigned char *eflag, Tri *ebsum, Tri *vbsum)
+                                               unsigned char *eflag, Tri *ebsum, Tri *vbsum, ZMarks Z, unsigned long long *dbg)
 {
     __shared__ Tri lds[16];
     Tri t{0, 0, 0};
     Tri tot;
+    __shared__ unsigned s_dbg[2];
+    if (dbg && threadIdx.x == 0) { s_dbg[0] = 0; s_dbg[1] = 0; }
+    const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
+    struct Fin { unsigned long long *dbg, t0; unsigned *sd; __device__ ~Fin() {
+        if (dbg && threadIdx.x == 0) {       // profiling aid: slowest block, slowest crossing / marking lane (100 MHz ticks)
+            const unsigned long long dt = wall_clock64() - t0;
+            if (dt > 500) atomicMax(&dbg[0], (dt << 32) | blockIdx.x);
+            if (sd[0] > 300) atomicMax(&dbg[10], (unsigned long long)sd[0]);
+            if (sd[1] > 300) atomicMax(&dbg[11], (unsigned long long)sd[1]);
+        } } } fin{dbg, t_start, s_dbg};
     if ((int)blockIdx.x < nbe) {
         const int ne = ne_dev ? *ne_dev : ne_ub;
         const int e = blockIdx.x * PB + threadIdx.x;
         if (e < ne) {
             unsigned char f;
             const int2 ed = E[e];
+            const unsigned long long ta = dbg ? wall_clock64() : 0ull;
             t = edge_triple(P, ed, &f);
             eflag[e] = f;
-            if (f == 4 && counters[0] > 0) mark_keep(P, ed);
+            const unsigned long long tb = dbg ? wall_clock64() : 0ull;
+            if (f == 4 && counters[0] > 0) mark_keep(P, ed, Z, counters);
+            if (dbg && f >= 2) { const unsigned long long tc = wall_clock64(); if (f != 4) atomicMax(&s_dbg[0], (unsigned)(tb - ta)); else atomicMax(&s_dbg[1], (unsigned)(tc - tb)); }
         }
         (void)block_exscan(t, &tot, lds);
         if (threadIdx.x == 0) ebsum[blockIdx.x] = tot;
@@ -942,7 +990,7 @@ __global__ __launch_bounds__(1024) void k_scan2(Tri *ebsum, int nbe, Tri *vbsum,
 template <int D>
 __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, const int2 *E, int ne_ub, const int *ne_dev, int nbe,
                                               const unsigned char *eflag, const Tri *ebpre, const Tri *vbpre, const Tri *totals,
-                                              int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members)
+                                              int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members, ZMarks Z, const int *counters)
 {
     __shared__ Tri lds[16];
     Tri t{0, 0, 0};
@@ -1050,12 +1098,15 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             todo &= todo - 1;
             const unsigned oo = __shfl(off_old, src, WAVE), on = __shfl(off_new, src, WAVE);
             const int nn = __shfl(n, src, WAVE), vv = __shfl(i, src, WAVE);
+            const int zid = zmarks_find(Z, counters, vv);
+            const int *row = zid >= 0 ? Z.rows + (size_t)zid * Z.stride : nullptr;
             int base = 0;
             for (int j0 = 0; j0 < nn; j0 += WAVE) {
                 const int j = j0 + lane;
-                const bool k = j < nn && P.keep[oo + j];
+                const int g = j < nn ? P.pool[oo + j] : 0;
+                const bool k = j < nn && (row ? row[g] == Z.stamp : P.keep[oo + j] != 0);
                 const unsigned long long bm = __ballot(k);
-                if (k) { P.pool[on + base + __popcll(bm & ((1ull << lane) - 1ull))] = P.pool[oo + j]; P.keep[oo + j] = 0; }
+                if (k) { P.pool[on + base + __popcll(bm & ((1ull << lane) - 1ull))] = g; if (!row) P.keep[oo + j] = 0; }
                 base += __popcll(bm);
             }
             if (lane == 0) { P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; }
@@ -1433,8 +1484,10 @@ struct bslv_poly {
     int *ne_dev = nullptr;            // edge count as the device knows it (written by k2_fused)
     bool pend_k2 = false;             // a k2_fused is in flight: ne is an upper bound
     int pend_seq = 0, pend_ebase = 0, pend_nm = 0, pend_stamp = 0; long long pend_len_ub = 0;
-    int pre_f = -1, pre_slot = 0, pre_nv = 0;   // halfspace already classified (queued behind the previous cut's k_emit2)
+    int *zlist = nullptr, *zrows = nullptr;     // ZMarks: CRING x ZMAX element ids, ZMAX x fcap facet stamps
+    int pre_f = -1, pre_slot = 0, pre_nv = 0, pre_seq = 0;   // halfspace already classified (queued behind the previous cut's k_emit2)
     unsigned long long *k2dbg = nullptr;   // BSLV_K2_DEBUG=1: per-phase clock sums of k2_fused (100 MHz ticks), printed at destroy
+    unsigned long long *fdbg = nullptr; long nflagslaunch = 0;   // with BSLV_CUT_LOG: per-launch block timing of k_flags2
     FILE *cutlog = nullptr;           // BSLV_CUT_LOG=<file>: one line per cut (nv ne nminus nzero zero_ub nsurv ncross newlen), profiling aid
     PairBlk *blks = nullptr; int blkcap = 0;
     unsigned char *pflag = nullptr; size_t pflagcap = 0;
@@ -1689,8 +1742,21 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
     memset(&hp, 0, sizeof(hp));
     memcpy(hp.h, &h->hp[(size_t)f * (d + 1)], (d + 1) * sizeof(double));
     int rc;
+    {   // arrays indexed by facet rank: this cut may add one
+        const int nranks = (int)h->facet_of_rank.size() + 1;
+        if (nranks > h->fcap) {
+            int nc = std::max(nranks + 1024, h->fcap * 2);
+            if ((rc = grow(&h->fstamp, (size_t)h->fcap, (size_t)nc, s, true))) return rc;
+            if ((rc = grow(&h->flocal, 0, (size_t)nc, s))) return rc;
+            if ((rc = grow(&h->zrows, 0, (size_t)ZMAX * nc, s, true))) return rc;      // fresh zeros: below every stamp
+            if (!h->nlocal && (rc = grow(&h->nlocal, 0, 4, s, true))) return rc;
+            h->fcap = nc;
+            h->pre_f = -1;                           // (its stamps went with the old rows)
+        }
+    }
     bool classified = h->pre_f == f && h->pre_nv == nv0;
     int cslot = classified ? h->pre_slot : next_counter_slot(h);
+    int cut_id = classified ? h->pre_seq : (int)h->cutseq;       // unique per classification: stamp of the ZMarks rows
     h->pre_f = -1;
     if (cslot < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
     const int nbv = (nv0 + PB - 1) / PB;
@@ -1707,8 +1773,9 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         // room for the survivors + crossing edges (<= ne) and every pair of a small facet (k2_fused emits in place)
         if ((rc = ensure_ecap(h, ne_ub + K2_MAXNM * (K2_MAXNM - 1) / 2 + 1))) return rc;
         // ---- round A ----
-        if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters);
-        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, ebsum, vbsum);
+        const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
+        if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters, h->zlist + ZMAX * cslot);
+        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, ebsum, vbsum, Z, h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
         const int seqA = ++h->mailseq;
         hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA);
         HIP_TRY(hipGetLastError());
@@ -1719,7 +1786,10 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         // the previous prune was redone by the multi-kernel path: classify and flag again on the complete edge list
         classified = false;
         if ((cslot = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
+        cut_id = (int)h->cutseq;
     }
+    const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
+    const int *counters = h->counters + 4 * cslot;
     nminus = h->mail_h[0].cnt[0]; nzero = h->mail_h[0].cnt[1]; zero_ub = h->mail_h[0].cnt[2];
     te = h->mail_h[0].t;
     const int ne0 = h->ne;
@@ -1736,10 +1806,10 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
     int2 *Enew = h->E[1 - h->ecur];
     // ---- round B ----
     switch (d) {
-#define CASE(D) case D: hipLaunchKernelGGL(k_emit2<D>, dim3(nbe + nbv), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, (const int *)nullptr, nbe, h->eflag, ebsum, vbsum, h->totals + 0, Enew, nv0, pool_e, pool_z, h->members); break;
+#define CASE(D) case D: hipLaunchKernelGGL(k_emit2<D>, dim3(nbe + nbv), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, (const int *)nullptr, nbe, h->eflag, ebsum, vbsum, h->totals + 0, Enew, nv0, pool_e, pool_z, h->members, Z, counters); break;
         CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
-    default: hipLaunchKernelGGL(k_emit2<0>, dim3(nbe + nbv), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, (const int *)nullptr, nbe, h->eflag, ebsum, vbsum, h->totals + 0, Enew, nv0, pool_e, pool_z, h->members); break;
+    default: hipLaunchKernelGGL(k_emit2<0>, dim3(nbe + nbv), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, (const int *)nullptr, nbe, h->eflag, ebsum, vbsum, h->totals + 0, Enew, nv0, pool_e, pool_z, h->members, Z, counters); break;
     }
     h->poolused += (unsigned)te.c + (unsigned)zero_ub;
     h->nv = nv0 + ncross;
@@ -1754,20 +1824,12 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         memcpy(hn.h, &h->hp[(size_t)next_f * (d + 1)], (d + 1) * sizeof(double));
         const int ns = next_counter_slot(h);
         if (ns < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-        hipLaunchKernelGGL(k_classify, dim3((h->nv + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + 4 * ns);
-        h->pre_f = next_f; h->pre_slot = ns; h->pre_nv = h->nv;
+        hipLaunchKernelGGL(k_classify, dim3((h->nv + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + 4 * ns, h->zlist + ZMAX * ns);
+        h->pre_f = next_f; h->pre_slot = ns; h->pre_nv = h->nv; h->pre_seq = (int)h->cutseq;
     }
     const int nm = nzero + ncross;
     if (nm >= 2) {
         h->pair_tests += (long)nm * (nm - 1) / 2;
-        const int nranks = (int)h->facet_of_rank.size();
-        if (nranks > h->fcap) {
-            int nc = std::max(nranks + 1024, h->fcap * 2);
-            if ((rc = grow(&h->fstamp, (size_t)h->fcap, (size_t)nc, s, true))) return rc;
-            if ((rc = grow(&h->flocal, 0, (size_t)nc, s))) return rc;
-            if (!h->nlocal && (rc = grow(&h->nlocal, 0, 4, s, true))) return rc;
-            h->fcap = nc;
-        }
         const long long len_ub = (long long)te.c + zero_ub;
         if (nm <= K2_MAXNM) {
             const int seqB = ++h->mailseq;
@@ -1860,7 +1922,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     h->P.d = dim;
     auto fail = [&](int code) { bslv_poly_destroy(h); return code; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
-    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess ||
+    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->zlist, CRING * ZMAX * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->mail_h, 4 * sizeof(Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&h->mail_d, h->mail_h, 0) != hipSuccess ||
@@ -1875,6 +1937,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
         h->k2_lds = 48 * 1024;
     }
     if (const char *cl = getenv("BSLV_CUT_LOG")) h->cutlog = fopen(cl, "w");
+    if (h->cutlog && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->fdbg, 0, 8192 * 16 * sizeof(unsigned long long));
     if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
     // dual slot 0: "facet at infinity", ideal point (0,..,0,-1)  (bslv_poly.c:83-92)
@@ -1888,6 +1951,15 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
 void bslv_poly_destroy(bslv_poly *h)
 {
     if (!h) return;
+    if (h->cutlog && h->fdbg) {
+        std::vector<unsigned long long> t(8192 * 16);
+        if (hipMemcpy(t.data(), h->fdbg, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            for (long k = 0; k < std::min<long>(h->nflagslaunch, 8192); k++)
+                { fprintf(h->cutlog, "F %ld %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", k, t[16 * k] >> 32, t[16 * k] & 0xffffffffull, t[16 * k + 1], t[16 * k + 2],
+                        t[16 * k + 3], t[16 * k + 4], t[16 * k + 5], t[16 * k + 6], t[16 * k + 7], t[16 * k + 8], t[16 * k + 9]);
+                fprintf(h->cutlog, "G %ld %llu %llu\n", k, t[16 * k + 10], t[16 * k + 11]); }
+        (void)hipFree(h->fdbg);
+    }
     if (h->cutlog) fclose(h->cutlog);
     if (h->k2dbg) {
         unsigned long long t[16];
@@ -1898,7 +1970,7 @@ void bslv_poly_destroy(bslv_poly *h)
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
-    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->zlist); fr(h->zrows);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
