@@ -932,9 +932,12 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
             if (sd[0] > 300) atomicMax(&dbg[10], (unsigned long long)sd[0]);
             if (sd[1] > 300) atomicMax(&dbg[11], (unsigned long long)sd[1]);
         } } } fin{dbg, t_start, s_dbg};
+    // blocks run back to front: the edges and elements the recent cuts created -- where the next cut acts, with the
+    // long dependent chains -- sit at the end of the arrays and must not wait for a second wave of workgroups
     if ((int)blockIdx.x < nbe) {
+        const int eb = nbe - 1 - (int)blockIdx.x;
         const int ne = ne_dev ? *ne_dev : ne_ub;
-        const int e = blockIdx.x * PB + threadIdx.x;
+        const int e = eb * PB + threadIdx.x;
         if (e < ne) {
             unsigned char f;
             const int2 ed = E[e];
@@ -946,9 +949,9 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
             if (dbg && f >= 2) { const unsigned long long tc = wall_clock64(); if (f != 4) atomicMax(&s_dbg[0], (unsigned)(tb - ta)); else atomicMax(&s_dbg[1], (unsigned)(tc - tb)); }
         }
         (void)block_exscan(t, &tot, lds);
-        if (threadIdx.x == 0) ebsum[blockIdx.x] = tot;
+        if (threadIdx.x == 0) ebsum[eb] = tot;
     } else {
-        const int b = blockIdx.x - nbe, i = b * PB + threadIdx.x;
+        const int b = (int)gridDim.x - 1 - (int)blockIdx.x, i = b * PB + threadIdx.x;
         if (i < nv0 && P.cls[i] == 0) { t.a = 1; t.c = P.inc_len[i] + 1; }
         (void)block_exscan(t, &tot, lds);
         if (threadIdx.x == 0) vbsum[b] = tot;
@@ -995,9 +998,10 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
     __shared__ Tri lds[16];
     Tri t{0, 0, 0};
     Tri tot;
-    if ((int)blockIdx.x < nbe) {
+    if ((int)blockIdx.x < nbe) {              // back to front, as k_flags2
+        const int eb = nbe - 1 - (int)blockIdx.x;
         const int ne = ne_dev ? *ne_dev : ne_ub;
-        const int e = blockIdx.x * PB + threadIdx.x;
+        const int e = eb * PB + threadIdx.x;
         unsigned char f = 0;
         int2 ed{0, 0};
         if (e < ne) {
@@ -1010,7 +1014,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
         }
         Tri ex = block_exscan(t, &tot, lds);
         if (e >= ne) return;
-        ex = tri_add(ex, ebpre[blockIdx.x]);
+        ex = tri_add(ex, ebpre[eb]);
         const int d = D > 0 ? D : P.d;
         if (f == 1 || f == 4) Enew[ex.a] = ed;
         else if (f == 2 || f == 3) {
@@ -1079,7 +1083,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
         return;
     }
     // ---- vertex blocks ----
-    const int b = blockIdx.x - nbe, i = b * PB + threadIdx.x, lane = threadIdx.x & 63;
+    const int b = (int)gridDim.x - 1 - (int)blockIdx.x, i = b * PB + threadIdx.x, lane = threadIdx.x & 63;
     signed char c = 2;
     int n = 0;
     unsigned off_old = 0;
@@ -1138,9 +1142,10 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
 // ---- K2 in ONE workgroup: the adjacency prune over the members of the new facet (bslv_poly.c:482-540) ----
 // Facets that occur in fewer than two member lists can never be mutual, so only the others get a local id:
 // the bit matrix then fits in LDS even though the extreme directions carry lists of thousands of facets.
-//   P1 mark facets seen twice   P2 local ids   P3 bit matrix (LDS)   P4 candidate pairs (>= d-1 mutual facets)
-//   P5 superset sweeps, one wave per candidate   P6 ordered emission at E[ebase..)
-// fstamp[g] in {S0 seen once, S0+1 seen twice, S0+2 id assigned}, S0 = 4 * cut sequence number (monotone, no reset).
+//   P1 count the member lists of each facet; the second arrival assigns the local id (fcount, zeroed again below)
+//   P3 bit matrix columns (per member) and rows (per local facet) in LDS
+//   P4 pairs: >= d-1 mutual facets and no third member on all of them (row intersection)
+//   P6 ordered emission at E[ebase..)
 // Falls back (mail t.b = 1) when the bit matrix does not fit; the host then runs the multi-kernel path.
 constexpr int K2T = 1024, K2_MAXNM = 512, K2_MAXLONG = 64;
 __device__ __forceinline__ void pair_decode(long long p, int nm, int &i, int &j)
@@ -1152,6 +1157,17 @@ __device__ __forceinline__ void pair_decode(long long p, int nm, int &i, int &j)
     while ((long long)(ii + 1) * (2 * nm - ii - 2) / 2 <= p) ii++;
     i = ii;
     j = ii + 1 + (int)(p - (long long)ii * (2 * nm - ii - 1) / 2);
+}
+// same for nm <= K2_MAXNM (p < 2^17): single-precision root, exact integer fix-up
+__device__ __forceinline__ void pair_decode32(int p, int nm, int &i, int &j)
+{
+    const float b2 = 2.0f * nm - 1.0f;
+    int ii = (int)((b2 - sqrtf(b2 * b2 - 8.0f * (float)p)) * 0.5f);
+    ii = ii < 0 ? 0 : (ii > nm - 2 ? nm - 2 : ii);
+    while (ii * (2 * nm - ii - 1) / 2 > p) ii--;
+    while ((ii + 1) * (2 * nm - ii - 2) / 2 <= p) ii++;
+    i = ii;
+    j = ii + 1 + (p - ii * (2 * nm - ii - 1) / 2);
 }
 template <class F>
 __device__ __forceinline__ void k2_for_entries(const int *pool, int nm, const unsigned *s_off, const int *s_len, const unsigned char *s_islong,
@@ -1176,41 +1192,59 @@ __device__ __forceinline__ void k2_for_entries(const int *pool, int nm, const un
 // sweep over all members (the sweep, one dependent LDS read per member, cost 25 us per cut).
 // NWC = compile-time bound of the row length in words, so the accumulator stays in registers.
 template <int NWC>
-__device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const unsigned long long *bits, const unsigned long long *rows, unsigned *adj_bits)
+__device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const unsigned long long *bits, const unsigned long long *rows, unsigned *adj_bits,
+                                         int (*queue)[128])
 {
-    const int npairs = nm * (nm - 1) / 2;
-    if ((int)threadIdx.x >= npairs) return;
-    int i, j;
-    pair_decode(threadIdx.x, nm, i, j);
-    for (int p = threadIdx.x; p < npairs; p += K2T) {
-        int nmut = 0;
-        for (int w = 0; w < W; w++) nmut += __popcll(bits[w * nm + i] & bits[w * nm + j]);
-        bool adj = d == 1 || nmut >= d - 1;
-        if (adj && d > 1) {
-            unsigned long long acc[NWC];
+    const int npairs = nm * (nm - 1) / 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the row intersection of one candidate
+    auto sweep = [&](int p) {
+        int i, j;
+        pair_decode32(p, nm, i, j);
+        unsigned long long acc[NWC];
 #pragma unroll
-            for (int k = 0; k < NWC; k++) acc[k] = ~0ull;
-            for (int w = 0; w < W; w++) {
-                unsigned long long M = bits[w * nm + i] & bits[w * nm + j];
-                while (M) {
-                    const int f = (w << 6) + __ffsll((long long)M) - 1;
-                    M &= M - 1;
+        for (int k = 0; k < NWC; k++) acc[k] = ~0ull;
+        for (int w = 0; w < W; w++) {
+            unsigned long long M = bits[w * nm + i] & bits[w * nm + j];
+            while (M) {
+                const int f = (w << 6) + __ffsll((long long)M) - 1;
+                M &= M - 1;
 #pragma unroll
-                    for (int k = 0; k < NWC; k++) acc[k] &= (NWC == 1 || k < NW) ? rows[f * NW + k] : 0ull;
-                }
+                for (int k = 0; k < NWC; k++) acc[k] &= (NWC == 1 || k < NW) ? rows[f * NW + k] : 0ull;
             }
-            int cnt = 0;
-#pragma unroll
-            for (int k = 0; k < NWC; k++) cnt += __popcll(acc[k]);
-            adj = cnt == 2;                       // i and j themselves lie on all their mutual facets
         }
-        if (adj) atomicOr(&adj_bits[p >> 5], 1u << (p & 31));
-        // step K2T pairs ahead in the lexicographic order
-        j += K2T;
-        while (j >= nm && i < nm - 1) { j -= nm - 2 - i; i++; }
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < NWC; k++) cnt += __popcll(acc[k]);
+        if (cnt == 2) atomicOr(&adj_bits[p >> 5], 1u << (p & 31));       // i and j themselves lie on all their mutual facets
+    };
+    // Only a fraction of the pairs are candidates; sweeping them where they are found would leave most lanes of
+    // the wave idle, so each wave queues its candidates (LDS) and sweeps 64 at a time.
+    int qn = 0;                                    // wave-uniform
+    int *q = queue[wave];
+    for (int p0 = 0; p0 < npairs; p0 += K2T) {
+        const int p = p0 + (int)threadIdx.x;
+        bool cand = false;
+        if (p < npairs) {
+            int i, j;
+            pair_decode32(p, nm, i, j);
+            int nmut = 0;
+            for (int w = 0; w < W; w++) nmut += __popcll(bits[w * nm + i] & bits[w * nm + j]);
+            if (d == 1) atomicOr(&adj_bits[p >> 5], 1u << (p & 31));
+            else cand = nmut >= d - 1;
+        }
+        const unsigned long long bm = __ballot(cand);
+        if (cand) q[qn + __popcll(bm & ((1ull << lane) - 1ull))] = p;
+        qn += __popcll(bm);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (qn >= WAVE) {
+            qn -= WAVE;
+            sweep(q[qn + lane]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
     }
+    if (lane < qn) sweep(q[lane]);
 }
-__global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nzero, int nv0, int ncross, int S0, int *fstamp, int *flocal,
+__global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
                                                 int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg)
 {
     extern __shared__ unsigned long long k2_dyn[];
@@ -1221,8 +1255,8 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     __shared__ int s_len[K2_MAXNM], s_mem[K2_MAXNM], s_long[K2_MAXLONG];
     __shared__ unsigned char s_islong[K2_MAXNM];
     __shared__ int s_nlong, s_nloc, s_carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nm = nzero + ncross, d = P.d;
-    const int S1 = S0 + 1, S2 = S0 + 2;
+    __shared__ int s_queue[K2T / WAVE][128];      // candidate pairs per wave (k2_pairs)
+    const int tid = threadIdx.x, nm = nzero + ncross, d = P.d;
     const long long npairs = (long long)nm * (nm - 1) / 2;
     const int nadjw = (int)((npairs + 31) / 32);
     unsigned *adj_bits = (unsigned *)k2_dyn;
@@ -1242,27 +1276,18 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     __syncthreads();
     const int nlong = s_nlong < K2_MAXLONG ? s_nlong : K2_MAXLONG;
     K2_PHASE(0);
-    // P1
+    // P1: count the member lists a facet occurs in; the second one to arrive gives it its local id
     k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) {
-        if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= S1) return;
-        const int old = atomicMax(&fstamp[g], S0);
-        if (old == S0) atomicMax(&fstamp[g], S1);
+        if (atomicAdd(&fcount[g], 1) == 1) __hip_atomic_store(&flocal[g], atomicAdd(&s_nloc, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     });
     __threadfence_block();
     __syncthreads();
     K2_PHASE(1);
-    // P2
-    k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) {
-        if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S1) return;
-        const int old = atomicMax(&fstamp[g], S2);
-        if (old == S1) __hip_atomic_store(&flocal[g], atomicAdd(&s_nloc, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    });
-    __threadfence_block();
-    __syncthreads();
     K2_PHASE(2);
     const int W = (s_nloc + 63) >> 6, NW = (nm + 63) >> 6;
     unsigned long long *rows = bits + W * nm;        // rows[f * NW + k]: members on local facet f
     if ((long long)W * nm + (long long)W * 64 * NW > bits_cap) {             // uniform: every thread sees the same s_nloc
+        k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
         if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; mail->t = r; __threadfence_system(); mail->seq = seq; }
         return;
     }
@@ -1270,18 +1295,20 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     __syncthreads();
     // P3
     k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int m, int g) {
-        if (__hip_atomic_load(&fstamp[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S2) return;
+        if (__hip_atomic_load(&fcount[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2) return;
         const int id = __hip_atomic_load(&flocal[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicOr(&bits[(id >> 6) * nm + m], 1ull << (id & 63));
         atomicOr(&rows[id * NW + (m >> 6)], 1ull << (m & 63));
     });
     __syncthreads();
+    // the counts go back to zero for the next cut (plain stores, nothing waits for them)
+    k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
     K2_PHASE(3);
     // P4+P5 (k2_pairs)
-    if (NW <= 1) k2_pairs<1>(nm, d, W, NW, bits, rows, adj_bits);
-    else if (NW <= 2) k2_pairs<2>(nm, d, W, NW, bits, rows, adj_bits);
-    else if (NW <= 4) k2_pairs<4>(nm, d, W, NW, bits, rows, adj_bits);
-    else k2_pairs<K2_MAXNM / 64>(nm, d, W, NW, bits, rows, adj_bits);
+    if (NW <= 1) k2_pairs<1>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
+    else if (NW <= 2) k2_pairs<2>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
+    else if (NW <= 4) k2_pairs<4>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
+    else k2_pairs<K2_MAXNM / 64>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
     __syncthreads();
     K2_PHASE(4);
     K2_PHASE(5);
@@ -1484,6 +1511,7 @@ struct bslv_poly {
     int *ne_dev = nullptr;            // edge count as the device knows it (written by k2_fused)
     bool pend_k2 = false;             // a k2_fused is in flight: ne is an upper bound
     int pend_seq = 0, pend_ebase = 0, pend_nm = 0, pend_stamp = 0; long long pend_len_ub = 0;
+    int *fcount = nullptr;            // per facet rank: member lists it occurs in (k2_fused; zero between cuts)
     int *zlist = nullptr, *zrows = nullptr;     // ZMarks: CRING x ZMAX element ids, ZMAX x fcap facet stamps
     int pre_f = -1, pre_slot = 0, pre_nv = 0, pre_seq = 0;   // halfspace already classified (queued behind the previous cut's k_emit2)
     unsigned long long *k2dbg = nullptr;   // BSLV_K2_DEBUG=1: per-phase clock sums of k2_fused (100 MHz ticks), printed at destroy
@@ -1749,6 +1777,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             if ((rc = grow(&h->fstamp, (size_t)h->fcap, (size_t)nc, s, true))) return rc;
             if ((rc = grow(&h->flocal, 0, (size_t)nc, s))) return rc;
             if ((rc = grow(&h->zrows, 0, (size_t)ZMAX * nc, s, true))) return rc;      // fresh zeros: below every stamp
+            if ((rc = grow(&h->fcount, 0, (size_t)nc, s, true))) return rc;
             if (!h->nlocal && (rc = grow(&h->nlocal, 0, 4, s, true))) return rc;
             h->fcap = nc;
             h->pre_f = -1;                           // (its stamps went with the old rows)
@@ -1833,7 +1862,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         const long long len_ub = (long long)te.c + zero_ub;
         if (nm <= K2_MAXNM) {
             const int seqB = ++h->mailseq;
-            hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, 4 * my_seq, h->fstamp, h->flocal,
+            hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, h->fcount, h->flocal,
                                (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + 2, seqB, h->k2dbg);
             HIP_TRY(hipGetLastError());
             h->pend_k2 = true; h->pend_seq = seqB; h->pend_ebase = h->ne; h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_stamp = 4 * my_seq + 3;
@@ -1970,7 +1999,7 @@ void bslv_poly_destroy(bslv_poly *h)
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
-    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->zlist); fr(h->zrows);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->zlist); fr(h->zrows); fr(h->fcount);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
