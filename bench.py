@@ -74,6 +74,7 @@ def main():
         raise SystemExit("phase 2 start failed: vlp status %d" % st)
 
     pipe = None
+    phase_ms = [0.0, 0.0, 0.0]          # host wall clock of collect / LP batch / cut application (N=1, unpipelined)
 
     def one_step():
         if world > 1:
@@ -82,9 +83,14 @@ def main():
             s = pipe.step()
             s["lps"] = s["lps_solved"]
             return s
+        t0 = time.perf_counter()
         nl, nt = eng.collect(B, 0, 1)
+        t1 = time.perf_counter()
         rec, piv, ls = eng.solve_local(nl)
+        t2 = time.perf_counter()
         s = eng.apply(rec)
+        t3 = time.perf_counter()
+        phase_ms[0] += (t1 - t0) * 1e3; phase_ms[1] += (t2 - t1) * 1e3; phase_ms[2] += (t3 - t2) * 1e3
         s.update(n_local=nl, n_total=nt, pivots=piv, lockstep=ls)
         return s
 
@@ -111,6 +117,7 @@ def main():
         one_step()
 
     eng.lp_call("set_profile", True)
+    phase_ms[:] = [0.0, 0.0, 0.0]
     rounds0 = eng.poly_call("rounds_run")
     nv0 = eng.poly_call("counts")["new_vertices"]
     pt0 = eng.poly_call("counts")["pair_tests"]
@@ -193,7 +200,7 @@ def main():
                        "tableau_slot_bytes": slot_bytes, "pool_slots": 4 * B + 64, "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
-            "live_vertices": live, "poly_rounds": eng.poly_call("rounds_run") - rounds0, "lp_ms_rank0": round(lp_ms, 2), "update_kernel_ms_rank0": round(upd_ms, 2),
+            "live_vertices": live, "poly_rounds": eng.poly_call("rounds_run") - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": {"collect": round(phase_ms[0] / args.steps, 2), "lp": round(phase_ms[1] / args.steps, 2), "cuts": round(phase_ms[2] / args.steps, 2)}, "update_kernel_ms_rank0": round(upd_ms, 2),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

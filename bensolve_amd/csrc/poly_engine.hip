@@ -126,8 +126,9 @@ __device__ __forceinline__ int zmarks_find(const ZMarks &Z, const int *counters,
     for (int k = 0; k < nz; k++) if (Z.zlist[k] == v) return k;
     return -1;
 }
-__global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters, int *zlist)
+__global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters, int *zlist, const int *nv_dev = nullptr)
 {
+    if (nv_dev) nv = *nv_dev;          // queued before the host knew how many elements the previous cut adds
     int i = blockIdx.x * PB + threadIdx.x;
     int isminus = 0, iszero = 0, zlen = 0;
     if (i < nv) {
@@ -957,10 +958,16 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
         if (threadIdx.x == 0) vbsum[b] = tot;
     }
 }
+// What the host decides after round A, decided on the device as well, so that round B can be queued before the
+// host has seen the result (speculative launch): go = the cut removes something, every capacity suffices and the
+// adjacency prune of the previous cut did not ask for its fallback (abort flag).
+constexpr int CROSS_UB = 4096;         // new vertices a speculatively queued classification of the next cut covers
+struct CutDev { int go, nminus, nzero, zero_ub, nsurv, ncross, newlen, ne0, nv_new, ebase; unsigned pool_z; int pad; };
 // both scans in one launch: workgroup 0 the edge sums (-> totals[0], mail[0] with the classify counters and,
 // in cnt[3], the exact edge count this cut saw), workgroup 1 the vertex sums (-> totals[1])
 __global__ __launch_bounds__(1024) void k_scan2(Tri *ebsum, int nbe, Tri *vbsum, int nbv, Tri *totals, Mail *mail, const int *counters,
-                                                int ne_ub, const int *ne_dev, int seq)
+                                                int ne_ub, const int *ne_dev, int seq, CutDev *cd, const int *abort_flag, int nv0, int vcap,
+                                                unsigned poolused, unsigned poolcap)
 {
     __shared__ Tri lds[16];
     Tri *sums = blockIdx.x == 0 ? ebsum : vbsum;
@@ -978,9 +985,22 @@ __global__ __launch_bounds__(1024) void k_scan2(Tri *ebsum, int nbe, Tri *vbsum,
     if (threadIdx.x == 0) {
         totals[blockIdx.x] = carry;
         if (blockIdx.x == 0) {
+            const int ne0 = ne_dev ? *ne_dev : ne_ub;
+            if (cd) {
+                CutDev c;
+                c.nminus = counters[0]; c.nzero = counters[1]; c.zero_ub = counters[2];
+                c.nsurv = carry.a; c.ncross = carry.b; c.newlen = carry.c; c.ne0 = ne0;
+                c.go = c.nminus > 0 && !*abort_flag && c.ncross <= CROSS_UB && nv0 + c.ncross <= vcap &&
+                       (unsigned long long)poolused + (unsigned)c.newlen + (unsigned)c.zero_ub <= poolcap;
+                c.nv_new = c.go ? nv0 + c.ncross : nv0;
+                c.ebase = c.go ? c.nsurv + c.ncross : ne0;
+                c.pool_z = poolused + (unsigned)c.newlen;
+                c.pad = 0;
+                *cd = c;
+            }
             mail->t = carry;
             for (int k = 0; k < 3; k++) mail->cnt[k] = counters[k];
-            mail->cnt[3] = ne_dev ? *ne_dev : ne_ub;
+            mail->cnt[3] = ne0;
             __threadfence_system();
             mail->seq = seq;
         }
@@ -993,8 +1013,12 @@ __global__ __launch_bounds__(1024) void k_scan2(Tri *ebsum, int nbe, Tri *vbsum,
 template <int D>
 __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, const int2 *E, int ne_ub, const int *ne_dev, int nbe,
                                               const unsigned char *eflag, const Tri *ebpre, const Tri *vbpre, const Tri *totals,
-                                              int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members, ZMarks Z, const int *counters)
+                                              int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members, ZMarks Z, const int *counters, const CutDev *cd)
 {
+    if (cd) {                          // speculative launch: the device's own verdict on round A
+        if (!cd->go) return;
+        pool_z = cd->pool_z;
+    }
     __shared__ Tri lds[16];
     Tri t{0, 0, 0};
     Tri tot;
@@ -1245,9 +1269,27 @@ __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const uns
     if (lane < qn) sweep(q[lane]);
 }
 __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
-                                                int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg)
+                                                int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg,
+                                                const CutDev *cd, int *abort_flag)
 {
     extern __shared__ unsigned long long k2_dyn[];
+    if (cd) {                          // speculative launch: sizes from the device, nothing to do unless the cut goes ahead
+        nzero = cd->nzero; ncross = cd->ncross; ebase = cd->ebase;
+        const int nm_ = nzero + ncross;
+        if (!cd->go || nm_ < 2 || nm_ > K2_MAXNM) {
+            if (threadIdx.x == 0) {
+                const bool big = cd->go && nm_ > K2_MAXNM;       // needs the multi-kernel prune
+                Tri r{0, big ? 1 : 2, 0};
+                if (big) *abort_flag = 1;
+                totals[0] = r;
+                if (ne_dev) *ne_dev = ebase;
+                mail->t = r;
+                __threadfence_system();
+                mail->seq = seq;
+            }
+            return;
+        }
+    }
     unsigned long long t_prev = dbg ? wall_clock64() : 0ull;
 #define K2_PHASE(k) do { if (dbg && threadIdx.x == 0) { unsigned long long t_now = wall_clock64(); dbg[k] += t_now - t_prev; t_prev = t_now; } } while (0)
     __shared__ Tri lds[16];
@@ -1288,7 +1330,7 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     unsigned long long *rows = bits + W * nm;        // rows[f * NW + k]: members on local facet f
     if ((long long)W * nm + (long long)W * 64 * NW > bits_cap) {             // uniform: every thread sees the same s_nloc
         k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
-        if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; mail->t = r; __threadfence_system(); mail->seq = seq; }
+        if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; __threadfence_system(); mail->seq = seq; }
         return;
     }
     for (int w = tid; w < W * nm + W * 64 * NW; w += K2T) bits[w] = 0ull;
@@ -1488,6 +1530,7 @@ struct bslv_poly {
     RoundsBuf *rounds = nullptr;      // scratch of the multi-cut path
     int batch_mode = 1;               // 0: one cut at a time, 1: rounds of independent cuts
     long rounds_run = 0, conf_pairs = 0, conf_cuts = 0;
+    int dense_streak = 0, dense_skip = 0;   // adaptive skipping of the conflict pass (apply_cuts_rounds)
     int d = 0, v2h = 0;
     std::vector<double> c;
     hipStream_t stream = nullptr;
@@ -1510,7 +1553,11 @@ struct bslv_poly {
     size_t k2_lds = 0;                // dynamic LDS bytes granted to k2_fused
     int *ne_dev = nullptr;            // edge count as the device knows it (written by k2_fused)
     bool pend_k2 = false;             // a k2_fused is in flight: ne is an upper bound
-    int pend_seq = 0, pend_ebase = 0, pend_nm = 0, pend_stamp = 0; long long pend_len_ub = 0;
+    int pend_seq = 0, pend_slot = 2, pend_ebase = 0, pend_nm = 0, pend_stamp = 0, pend_nzero = 0, pend_nv0 = 0, pend_ncross = 0; long long pend_len_ub = 0;
+    int k2flip = 0;                   // the prune mailbox alternates between two slots: one result may wait while the next is queued
+    bool speculate = true;            // queue round B before the host has seen round A (BSLV_NO_SPEC=1 turns it off)
+    CutDev *cutdev = nullptr;         // CRING verdicts of k_scan2
+    int *abort_d = nullptr;           // set by a k2_fused that needs its fallback: everything queued behind it declines
     int *fcount = nullptr;            // per facet rank: member lists it occurs in (k2_fused; zero between cuts)
     int *zlist = nullptr, *zrows = nullptr;     // ZMarks: CRING x ZMAX element ids, ZMAX x fcap facet stamps
     int pre_f = -1, pre_slot = 0, pre_nv = 0, pre_seq = 0;   // halfspace already classified (queued behind the previous cut's k_emit2)
@@ -1730,22 +1777,26 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
 }
 
 // waits for the adjacency prune still in flight (k2_fused of the previous cut) and books its edges; when the
-// kernel reported that its bit matrix did not fit, runs the multi-kernel prune instead.  *redo (may be NULL) is
-// set in that case: whatever was launched behind the failed kernel saw an incomplete edge list.
+// kernel reported that its bit matrix did not fit (or the facet is too large for it), runs the multi-kernel
+// prune instead.  *redo (may be NULL) is set in that case: whatever was launched behind the failed kernel saw an
+// incomplete edge list (round B of the next cut, if queued speculatively, skipped itself: abort flag).
 static int settle_k2(bslv_poly *h, bool *redo = nullptr)
 {
     if (redo) *redo = false;
     if (!h->pend_k2) return 0;
     int rc;
-    if ((rc = wait_mail(h, 2, h->pend_seq))) return rc;
+    if ((rc = wait_mail(h, h->pend_slot, h->pend_seq))) return rc;
     h->pend_k2 = false;
-    const Tri tp = h->mail_h[2].t;
-    if (tp.b) {
-        h->ne = h->pend_ebase;
+    const Tri tp = h->mail_h[h->pend_slot].t;
+    h->ne = h->pend_ebase;
+    if (tp.b == 1) {
         if (redo) *redo = true;
+        HIP_TRY(hipMemsetAsync(h->abort_d, 0, sizeof(int), h->stream));
+        if (h->pend_ncross > 0)
+            hipLaunchKernelGGL(k_iota_members, dim3((h->pend_ncross + 255) / 256), dim3(256), 0, h->stream, h->members, h->pend_nzero, h->pend_nv0, h->pend_ncross);
         return k2_multi(h, h->pend_nm, h->pend_len_ub, h->pend_stamp);
     }
-    h->ne = h->pend_ebase + tp.a;
+    if (tp.b == 0) h->ne += tp.a;          // (2: the kernel had nothing to do)
     return 0;
 }
 static int next_counter_slot(bslv_poly *h)
@@ -1755,20 +1806,36 @@ static int next_counter_slot(bslv_poly *h)
     h->cutseq++;
     return cslot;
 }
+template <class... A>
+static void launch_emit2(int d, dim3 grid, hipStream_t s, A... a)
+{
+    switch (d) {
+#define CASE(D) case D: hipLaunchKernelGGL(k_emit2<D>, grid, dim3(PB), 0, s, a...); break;
+        CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+    default: hipLaunchKernelGGL(k_emit2<0>, grid, dim3(PB), 0, s, a...); break;
+    }
+}
 
-// one cut on the device; *rc = 0 cut applied, 1 redundant.  Five launches and ONE host round trip:
-//   [k_classify] k_flags2 k_scan2 -> host (redundant? capacities) -> k_emit2 [k_classify of next_f] k2_fused
-// The adjacency prune is left in flight: its pairs land behind the edges of this cut on the device, the next
-// cut reads the edge count from there (ne_dev) and the host books it at its next wait (settle_k2).  The
-// classification of the next halfspace is queued between k_emit2 and k2_fused, where its launch latency hides.
+// one cut on the device; *rc = 0 cut applied, 1 redundant.  Five launches:
+//   [k_classify] k_flags2 k_scan2 | k_emit2 [k_classify of next_f] k2_fused
+// Round B is queued BEFORE the host has read the result of round A (speculative launch): k_scan2 leaves the
+// verdict -- redundant? capacities? -- on the device (CutDev), the kernels of round B read their sizes from there and
+// return at once when the cut does not go ahead; the host reads the same numbers from its mailbox, reaches the same
+// verdict, and only when a capacity was short grows it and launches round B again with host arguments.
+// The adjacency prune stays in flight: its pairs land behind the edges of this cut on the device, the next cut
+// reads the edge count from there (ne_dev) and the host books it at its next wait (settle_k2).  The classification
+// of the next halfspace is queued between k_emit2 and k2_fused, where its launch latency hides.
 // Callers finish a sequence of cuts with settle_k2().
 static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
 {
     const int d = h->d, nv0 = h->nv;
     hipStream_t s = h->stream;
-    Hp hp;
+    Hp hp, hn;
     memset(&hp, 0, sizeof(hp));
     memcpy(hp.h, &h->hp[(size_t)f * (d + 1)], (d + 1) * sizeof(double));
+    memset(&hn, 0, sizeof(hn));
+    if (next_f >= 0) memcpy(hn.h, &h->hp[(size_t)next_f * (d + 1)], (d + 1) * sizeof(double));
     int rc;
     {   // arrays indexed by facet rank: this cut may add one
         const int nranks = (int)h->facet_of_rank.size() + 1;
@@ -1783,14 +1850,19 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             h->pre_f = -1;                           // (its stamps went with the old rows)
         }
     }
+    bool spec = h->speculate;
+    if (spec) {   // head-room that lets the device say yes: CROSS_UB new elements with their lists
+        if ((rc = ensure_vcap(h, nv0 + CROSS_UB))) return rc;
+        if ((rc = ensure_pool(h, (size_t)h->poolused + (size_t)CROSS_UB * 64))) return rc;
+    }
     bool classified = h->pre_f == f && h->pre_nv == nv0;
     int cslot = classified ? h->pre_slot : next_counter_slot(h);
     int cut_id = classified ? h->pre_seq : (int)h->cutseq;       // unique per classification: stamp of the ZMarks rows
     h->pre_f = -1;
     if (cslot < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
     const int nbv = (nv0 + PB - 1) / PB;
-    int nbe, nminus, nzero, zero_ub;
-    Tri te;
+    const int rank = (int)h->facet_of_rank.size();
+    int nbe, seqB = 0, slotB = 0, spec_ns = -1;
     Tri *ebsum, *vbsum;
     for (;;) {
         int *counters = h->counters + 4 * cslot;
@@ -1803,73 +1875,111 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         if ((rc = ensure_ecap(h, ne_ub + K2_MAXNM * (K2_MAXNM - 1) / 2 + 1))) return rc;
         // ---- round A ----
         const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
-        if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters, h->zlist + ZMAX * cslot);
+        CutDev *cd = h->cutdev + cslot;
+        if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters, h->zlist + ZMAX * cslot, (const int *)nullptr);
         hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, ebsum, vbsum, Z, h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
         const int seqA = ++h->mailseq;
-        hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA);
+        hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA,
+                           cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap);
+        if (spec) {
+            // ---- round B, queued on the device's own verdict ----
+            launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne_ub, ne_dev, nbe, (const unsigned char *)h->eflag, (const Tri *)ebsum, (const Tri *)vbsum,
+                         (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, h->poolused, 0u, h->members, Z, (const int *)counters, (const CutDev *)cd);
+            spec_ns = -1;
+            if (next_f >= 0) {
+                if ((spec_ns = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
+                hipLaunchKernelGGL(k_classify, dim3((nv0 + CROSS_UB + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, 0, h->counters + 4 * spec_ns, h->zlist + ZMAX * spec_ns,
+                                   (const int *)&cd->nv_new);
+                h->pre_seq = (int)h->cutseq;
+            }
+            seqB = ++h->mailseq;
+            slotB = 2 + (h->k2flip ^= 1);
+            hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
+                               h->ne_dev, h->totals + 2, h->mail_d + slotB, seqB, h->k2dbg, (const CutDev *)cd, h->abort_d);
+        }
         HIP_TRY(hipGetLastError());
         if ((rc = wait_mail(h, 0, seqA))) return rc;
         bool redo;
         if ((rc = settle_k2(h, &redo))) return rc;
+        if (!redo && spec && h->mail_h[0].cnt[0] > 0) {
+            // did the device decline round B for want of capacity?  Then its classification of the NEXT halfspace has
+            // already overwritten the classes of this one: book the declined prune, grow, and run the cut again
+            // without speculation
+            const Tri t0 = h->mail_h[0].t;
+            const int zub = h->mail_h[0].cnt[2];
+            if (!(t0.b <= CROSS_UB && nv0 + t0.b <= h->P.cap && (unsigned long long)h->poolused + (unsigned)t0.c + (unsigned)zub <= h->poolcap)) {
+                h->pend_k2 = true; h->pend_seq = seqB; h->pend_slot = slotB; h->pend_ebase = h->ne; h->pend_ncross = 0;
+                if ((rc = settle_k2(h))) return rc;
+                if ((rc = ensure_vcap(h, nv0 + t0.b))) return rc;
+                if ((rc = ensure_pool(h, (size_t)h->poolused + t0.c + zub))) return rc;
+                spec = false;
+                redo = true;
+            }
+        }
         if (!redo) break;
-        // the previous prune was redone by the multi-kernel path: classify and flag again on the complete edge list
+        // the previous prune was redone by the multi-kernel path (everything queued behind it skipped itself or was
+        // free of side effects), or this cut runs again without speculation: classify and flag again
         classified = false;
         if ((cslot = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
         cut_id = (int)h->cutseq;
     }
     const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
     const int *counters = h->counters + 4 * cslot;
-    nminus = h->mail_h[0].cnt[0]; nzero = h->mail_h[0].cnt[1]; zero_ub = h->mail_h[0].cnt[2];
-    te = h->mail_h[0].t;
+    const int nminus = h->mail_h[0].cnt[0], nzero = h->mail_h[0].cnt[1], zero_ub = h->mail_h[0].cnt[2];
+    const Tri te = h->mail_h[0].t;
     const int ne0 = h->ne;
     if (h->mail_h[0].cnt[3] != ne0) { set_error("internal: edge count on the device %d, on the host %d", h->mail_h[0].cnt[3], ne0); return BSLV_E_STATE; }
     if (h->cutlog) fprintf(h->cutlog, "%d %d %d %d %d %d %d %d\n", nv0, ne0, nminus, nzero, zero_ub, te.a, te.b, te.c);
-    if (nminus == 0) { h->fapplied[f] = 0; *rc_out = 1; return 0; }
-    const int rank = (int)h->facet_of_rank.size();
-    h->facet_of_rank.push_back(f);
     const int nsurv = te.a, ncross = te.b;
-    if ((rc = ensure_vcap(h, nv0 + ncross))) return rc;
-    if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
+    const int nm = nzero + ncross;
+    const long long len_ub = (long long)te.c + zero_ub;
+    const bool went = spec && nminus > 0;         // (capacities were checked in the loop, with the verdict of k_scan2)
+    if (spec) {   // the queued prune reports in any case (nothing to do / pairs / fallback): book it at the next wait
+        h->pend_k2 = true; h->pend_seq = seqB; h->pend_slot = slotB;
+        h->pend_ebase = went ? nsurv + ncross : ne0;
+        h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_nzero = nzero; h->pend_nv0 = nv0; h->pend_ncross = ncross;
+        if (spec_ns >= 0 && (went || nminus == 0)) { h->pre_f = next_f; h->pre_slot = spec_ns; h->pre_nv = went ? nv0 + ncross : nv0; }
+    }
+    if (nminus == 0) { h->fapplied[f] = 0; *rc_out = 1; return 0; }
+    h->facet_of_rank.push_back(f);
     const unsigned pool_e = h->poolused, pool_z = h->poolused + (unsigned)te.c;
-    const int2 *Eold = h->E[h->ecur];
-    int2 *Enew = h->E[1 - h->ecur];
-    // ---- round B ----
-    switch (d) {
-#define CASE(D) case D: hipLaunchKernelGGL(k_emit2<D>, dim3(nbe + nbv), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, (const int *)nullptr, nbe, h->eflag, ebsum, vbsum, h->totals + 0, Enew, nv0, pool_e, pool_z, h->members, Z, counters); break;
-        CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
-#undef CASE
-    default: hipLaunchKernelGGL(k_emit2<0>, dim3(nbe + nbv), dim3(PB), 0, s, h->P, hp, rank, Eold, ne0, (const int *)nullptr, nbe, h->eflag, ebsum, vbsum, h->totals + 0, Enew, nv0, pool_e, pool_z, h->members, Z, counters); break;
+    if (!went) {
+        // ---- round B with host arguments (no speculation, or a capacity was short and the device declined) ----
+        if ((rc = ensure_vcap(h, nv0 + ncross))) return rc;
+        if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
+        launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne0, (const int *)nullptr, nbe, (const unsigned char *)h->eflag, (const Tri *)ebsum, (const Tri *)vbsum,
+                     (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, pool_e, pool_z, h->members, Z, counters, (const CutDev *)nullptr);
     }
     h->poolused += (unsigned)te.c + (unsigned)zero_ub;
     h->nv = nv0 + ncross;
     h->ne = nsurv + ncross;
     h->ecur = 1 - h->ecur;
     h->new_vertices += ncross;
-    const int my_seq = (int)h->cutseq;           // fstamp states of this cut: 4*my_seq .. 4*my_seq+3
-    if (next_f >= 0) {
-        // classify the next halfspace now (the new vertices exist once k_emit2 has run; k2 does not read classes)
-        Hp hn;
-        memset(&hn, 0, sizeof(hn));
-        memcpy(hn.h, &h->hp[(size_t)next_f * (d + 1)], (d + 1) * sizeof(double));
-        const int ns = next_counter_slot(h);
-        if (ns < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-        hipLaunchKernelGGL(k_classify, dim3((h->nv + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + 4 * ns, h->zlist + ZMAX * ns);
-        h->pre_f = next_f; h->pre_slot = ns; h->pre_nv = h->nv; h->pre_seq = (int)h->cutseq;
-    }
-    const int nm = nzero + ncross;
-    if (nm >= 2) {
-        h->pair_tests += (long)nm * (nm - 1) / 2;
-        const long long len_ub = (long long)te.c + zero_ub;
-        if (nm <= K2_MAXNM) {
-            const int seqB = ++h->mailseq;
-            hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, h->fcount, h->flocal,
-                               (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + 2, seqB, h->k2dbg);
-            HIP_TRY(hipGetLastError());
-            h->pend_k2 = true; h->pend_seq = seqB; h->pend_ebase = h->ne; h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_stamp = 4 * my_seq + 3;
-            h->ne += (int)((long long)nm * (nm - 1) / 2);          // upper bound until settle_k2
-        } else {
-            if (ncross > 0) hipLaunchKernelGGL(k_iota_members, dim3((ncross + 255) / 256), dim3(256), 0, s, h->members, nzero, nv0, ncross);
-            if ((rc = k2_multi(h, nm, len_ub, 4 * my_seq + 3))) return rc;
+    h->pend_stamp = (int)(4 * h->cutseq + 3);     // fstamp value of a fallback prune for this cut (monotone)
+    if (nm >= 2) h->pair_tests += (long)nm * (nm - 1) / 2;
+    if (went) {
+        if (nm >= 2 && nm <= K2_MAXNM) h->ne += (int)((long long)nm * (nm - 1) / 2);      // upper bound until settle_k2
+    } else {
+        if (next_f >= 0) {
+            // classify the next halfspace now (the new vertices exist once k_emit2 has run; k2 does not read classes)
+            const int ns = next_counter_slot(h);
+            if (ns < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
+            hipLaunchKernelGGL(k_classify, dim3((h->nv + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + 4 * ns, h->zlist + ZMAX * ns, (const int *)nullptr);
+            h->pre_f = next_f; h->pre_slot = ns; h->pre_nv = h->nv; h->pre_seq = (int)h->cutseq;
+        }
+        if (nm >= 2) {
+            if (nm <= K2_MAXNM) {
+                const int sq = ++h->mailseq, sl = 2 + (h->k2flip ^= 1);
+                hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, h->fcount, h->flocal,
+                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + sl, sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d);
+                HIP_TRY(hipGetLastError());
+                h->pend_k2 = true; h->pend_seq = sq; h->pend_slot = sl; h->pend_ebase = h->ne;
+                h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_nzero = nzero; h->pend_nv0 = nv0; h->pend_ncross = ncross;
+                h->ne += (int)((long long)nm * (nm - 1) / 2);          // upper bound until settle_k2
+            } else {
+                if (ncross > 0) hipLaunchKernelGGL(k_iota_members, dim3((ncross + 255) / 256), dim3(256), 0, s, h->members, nzero, nv0, ncross);
+                if ((rc = k2_multi(h, nm, len_ub, h->pend_stamp))) return rc;
+            }
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1951,7 +2061,8 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     h->P.d = dim;
     auto fail = [&](int code) { bslv_poly_destroy(h); return code; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
-    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->zlist, CRING * ZMAX * sizeof(int)) != hipSuccess ||
+    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->cutdev, CRING * sizeof(CutDev)) != hipSuccess ||
+        hipMalloc(&h->abort_d, 4 * sizeof(int)) != hipSuccess || hipMemset(h->abort_d, 0, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->zlist, CRING * ZMAX * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->mail_h, 4 * sizeof(Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&h->mail_d, h->mail_h, 0) != hipSuccess ||
@@ -1966,6 +2077,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
         h->k2_lds = 48 * 1024;
     }
     if (const char *cl = getenv("BSLV_CUT_LOG")) h->cutlog = fopen(cl, "w");
+    if (getenv("BSLV_NO_SPEC")) h->speculate = false;
     if (h->cutlog && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->fdbg, 0, 8192 * 16 * sizeof(unsigned long long));
     if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
@@ -1999,7 +2111,7 @@ void bslv_poly_destroy(bslv_poly *h)
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
-    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->zlist); fr(h->zrows); fr(h->fcount);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
