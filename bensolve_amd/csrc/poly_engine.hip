@@ -40,7 +40,14 @@ struct PolyView {
     int *inc_len;           // cap
     int *pool;              // poolcap
     unsigned char *keep;    // poolcap (all zero between cuts)
+    // hot mode (a chunk of cuts whose batched classification is known): the per-cut element passes only visit the
+    // elements some cut of the chunk does not leave strictly inside (hv, ascending ids) and those created since
+    // the chunk began (ids >= nv_base); everything else is PLUS for every cut of the chunk.  hv == nullptr: all.
+    const int *hv;
+    int nhv, nv_base;
 };
+__device__ __host__ inline int vm_count(const PolyView &P, int nv) { return P.hv ? P.nhv + (nv - P.nv_base) : nv; }
+__device__ __forceinline__ int vm_id(const PolyView &P, int idx) { return P.hv ? (idx < P.nhv ? P.hv[idx] : P.nv_base + (idx - P.nhv)) : idx; }
 
 // ---------------- scans ----------------
 __device__ __forceinline__ Tri tri_add(Tri x, Tri y) { return Tri{x.a + y.a, x.b + y.b, x.c + y.c}; }
@@ -129,9 +136,10 @@ __device__ __forceinline__ int zmarks_find(const ZMarks &Z, const int *counters,
 __global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters, int *zlist, const int *nv_dev = nullptr)
 {
     if (nv_dev) nv = *nv_dev;          // queued before the host knew how many elements the previous cut adds
-    int i = blockIdx.x * PB + threadIdx.x;
+    const int idx = blockIdx.x * PB + threadIdx.x;
     int isminus = 0, iszero = 0, zlen = 0;
-    if (i < nv) {
+    if (idx < vm_count(P, nv)) {
+        const int i = vm_id(P, idx);
         unsigned char fl = P.flag[i];
         signed char c = 2;
         if (fl & F_USED) { c = classify_one(P, hp, i, fl); isminus = c < 0; iszero = c == 0; }
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned lo
 }
 
 __global__ __launch_bounds__(PB) void k_pair_emit(const int *members, int nm, const PairBlk *blks, const unsigned char *pflag,
-                                                   const Tri *bpre, int2 *E, int ebase)
+                                                   const Tri *bpre, int2 *E, int ebase, int *EP = nullptr)
 {
     __shared__ Tri lds[16];
     const PairBlk pb = blks ? blks[blockIdx.x] : pair_block(nm, blockIdx.x);
@@ -842,6 +850,7 @@ __global__ __launch_bounds__(PB) void k_pair_emit(const int *members, int nm, co
     Tri ex = block_exscan(t, &tot, lds);
     if (!f) return;
     E[ebase + bpre[blockIdx.x].a + ex.a] = int2{members[pb.i], members[pb.j0 + threadIdx.x]};
+    if (EP) EP[ebase + bpre[blockIdx.x].a + ex.a] = -1;
 }
 
 
@@ -918,7 +927,7 @@ __device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed, cons
 // ne_dev != nullptr: the edge count of the previous cut is still on the device (its adjacent pairs were
 // appended without a host round trip); ne_ub then only sizes the grid.
 __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne_ub, const int *ne_dev, int nbe, int nv0, const int *counters,
-                                               unsigned char *eflag, Tri *ebsum, Tri *vbsum, ZMarks Z, unsigned long long *dbg)
+                                               unsigned char *eflag, int *ecount, Tri *ebsum, Tri *vbsum, ZMarks Z, unsigned long long *dbg)
 {
     __shared__ Tri lds[16];
     Tri t{0, 0, 0};
@@ -940,20 +949,38 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
         const int ne = ne_dev ? *ne_dev : ne_ub;
         const int e = eb * PB + threadIdx.x;
         if (e < ne) {
-            unsigned char f;
             const int2 ed = E[e];
-            const unsigned long long ta = dbg ? wall_clock64() : 0ull;
-            t = edge_triple(P, ed, &f);
+            const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
+            unsigned char f = 0;
+            if ((ca == -1 && cb == 1) || (ca == 1 && cb == -1)) { f = (ca == -1) ? 2 : 3; t.b = 1; }
+            else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = (ca == 0 || cb == 0) ? 4 : 1; t.a = 1; }
             eflag[e] = f;
-            const unsigned long long tb = dbg ? wall_clock64() : 0ull;
-            if (f == 4 && counters[0] > 0) mark_keep(P, ed, Z, counters);
-            if (dbg && f >= 2) { const unsigned long long tc = wall_clock64(); if (f != 4) atomicMax(&s_dbg[0], (unsigned)(tb - ta)); else atomicMax(&s_dbg[1], (unsigned)(tc - tb)); }
+            const bool cross = f == 2 || f == 3, mark = f == 4 && counters[0] > 0;
+            if (cross || mark) {
+                // both need the intersection of the two incidence lists -- a crossing edge its size (the list of the new
+                // vertex), a ZERO-PLUS edge the positions in the ZERO element's list (its keep marks): one shared
+                // code path, so that a wave holding edges of both kinds does not walk two chains one after the other
+                const int ia = (mark && ca != 0) ? ed.y : ed.x, ib = ia == ed.x ? ed.y : ed.x;      // A = the ZERO element of a marking edge
+                const int na = P.inc_len[ia], nb = P.inc_len[ib];
+                if (na <= LCAP && nb <= LCAP) {
+                    int RA[LCAP], RB[LCAP];
+                    load_list(P.pool + P.inc_off[ia], na, RA); load_list(P.pool + P.inc_off[ib], nb, RB);
+                    unsigned m = match_mask(RA, na, RB);
+                    if (cross) t.c = __popc(m) + 1;
+                    else {
+                        unsigned char *K = P.keep + P.inc_off[ia];
+                        while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; set_keep(K, a); }
+                    }
+                } else if (cross) t.c = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
+                else mark_keep(P, ed, Z, counters);
+                if (cross) ecount[e] = t.c;
+            }
         }
         (void)block_exscan(t, &tot, lds);
         if (threadIdx.x == 0) ebsum[eb] = tot;
     } else {
-        const int b = (int)gridDim.x - 1 - (int)blockIdx.x, i = b * PB + threadIdx.x;
-        if (i < nv0 && P.cls[i] == 0) { t.a = 1; t.c = P.inc_len[i] + 1; }
+        const int b = (int)gridDim.x - 1 - (int)blockIdx.x, idx = b * PB + threadIdx.x;
+        if (idx < vm_count(P, nv0)) { const int i = vm_id(P, idx); if (P.cls[i] == 0) { t.a = 1; t.c = P.inc_len[i] + 1; } }
         (void)block_exscan(t, &tot, lds);
         if (threadIdx.x == 0) vbsum[b] = tot;
     }
@@ -1012,8 +1039,9 @@ __global__ __launch_bounds__(1024) void k_scan2(Tri *ebsum, int nbe, Tri *vbsum,
 // ZERO elements get their kept facets + the new one at pool[pool_z + prefix) and become members[0..nzero).
 template <int D>
 __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, const int2 *E, int ne_ub, const int *ne_dev, int nbe,
-                                              const unsigned char *eflag, const Tri *ebpre, const Tri *vbpre, const Tri *totals,
-                                              int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members, ZMarks Z, const int *counters, const CutDev *cd)
+                                              const unsigned char *eflag, const int *ecount, const Tri *ebpre, const Tri *vbpre, const Tri *totals,
+                                              int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members, ZMarks Z, const int *counters, const CutDev *cd,
+                                              const int *EPold, int *EPnew)
 {
     if (cd) {                          // speculative launch: the device's own verdict on round A
         if (!cd->go) return;
@@ -1031,16 +1059,13 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
         if (e < ne) {
             f = eflag[e]; ed = E[e];
             if (f == 1 || f == 4) t.a = 1;
-            else if (f >= 2) {
-                t.b = 1;
-                t.c = isect_count_fast(P.pool + P.inc_off[ed.x], P.inc_len[ed.x], P.pool + P.inc_off[ed.y], P.inc_len[ed.y]) + 1;
-            }
+            else if (f >= 2) { t.b = 1; t.c = ecount[e]; }        // list length of the new vertex, from k_flags2
         }
         Tri ex = block_exscan(t, &tot, lds);
         if (e >= ne) return;
         ex = tri_add(ex, ebpre[eb]);
         const int d = D > 0 ? D : P.d;
-        if (f == 1 || f == 4) Enew[ex.a] = ed;
+        if (f == 1 || f == 4) { Enew[ex.a] = ed; if (EPold) EPnew[ex.a] = EPold[e]; }      // (hot mode: where the edge sat before the chunk)
         else if (f == 2 || f == 3) {
             const int mi = (f == 2) ? ed.x : ed.y, pl = (f == 2) ? ed.y : ed.x;
             const int w = nv0 + ex.b;
@@ -1103,15 +1128,18 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             P.inc_off[w] = off;
             P.inc_len[w] = n;
             Enew[totals[0].a + ex.b] = int2{w, pl};
+            if (EPold) EPnew[totals[0].a + ex.b] = -1;
         }
         return;
     }
     // ---- vertex blocks ----
-    const int b = (int)gridDim.x - 1 - (int)blockIdx.x, i = b * PB + threadIdx.x, lane = threadIdx.x & 63;
+    const int b = (int)gridDim.x - 1 - (int)blockIdx.x, idx = b * PB + threadIdx.x, lane = threadIdx.x & 63;
+    const bool valid = idx < vm_count(P, nv0);
+    const int i = valid ? vm_id(P, idx) : -1;
     signed char c = 2;
     int n = 0;
     unsigned off_old = 0;
-    if (i < nv0) {
+    if (valid) {
         c = P.cls[i];
         if (c == 0) { off_old = P.inc_off[i]; n = P.inc_len[i]; t.a = 1; t.c = n + 1; }
     }
@@ -1140,7 +1168,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             if (lane == 0) { P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; }
         }
     }
-    if (i >= nv0) return;
+    if (!valid) return;
     if (c == -1) { P.flag[i] &= ~F_USED; return; }
     if (c != 0) return;
     members[ex.a] = i;
@@ -1270,7 +1298,7 @@ __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const uns
 }
 __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
                                                 int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg,
-                                                const CutDev *cd, int *abort_flag)
+                                                const CutDev *cd, int *abort_flag, int *EP)
 {
     extern __shared__ unsigned long long k2_dyn[];
     if (cd) {                          // speculative launch: sizes from the device, nothing to do unless the cut goes ahead
@@ -1367,7 +1395,7 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
             int i, j;
             pair_decode((long long)ww * 32, nm, i, j);
             for (int bbit = 0; bbit < 32; bbit++) {
-                if ((word >> bbit) & 1u) E[at++] = int2{s_mem[i], s_mem[j]};
+                if ((word >> bbit) & 1u) { E[at] = int2{s_mem[i], s_mem[j]}; if (EP) EP[at] = -1; at++; }
                 if (++j == nm) { i++; j = i + 1; }
             }
         }
@@ -1385,6 +1413,83 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
         __threadfence_system();
         mail->seq = seq;
     }
+}
+
+
+// ---------------- hot mode: set-up and merge (once per chunk of cuts) ----------------
+// elements some cut of the chunk touches (tc > 0, from k_classify_batch) -> hv (ascending); the others are PLUS for all
+__global__ __launch_bounds__(PB) void k_hotv_flags(PolyView P, const int *tc, int nv, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    const int i = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (i < nv) t.a = (P.flag[i] & F_USED) && tc[i] > 0;
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_hotv_emit(PolyView P, const int *tc, int nv, const Tri *bpre, int *hv)
+{
+    __shared__ Tri lds[16];
+    const int i = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (i < nv) { t.a = (P.flag[i] & F_USED) && tc[i] > 0; if (!t.a) P.cls[i] = 1; }
+    Tri tot;
+    Tri ex = block_exscan(t, &tot, lds);
+    if (t.a) hv[bpre[blockIdx.x].a + ex.a] = i;
+}
+// edges with a touched end -> EH (order kept) with their position in E; alive[e] = 1 for the others
+__global__ __launch_bounds__(PB) void k_hote_flags(const int2 *E, int ne, const int *tc, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    const int e = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (e < ne) { const int2 ed = E[e]; t.a = tc[ed.x] > 0 || tc[ed.y] > 0; }
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_hote_emit(const int2 *E, int ne, const int *tc, const Tri *bpre, int2 *EH, int *EP, unsigned char *alive)
+{
+    __shared__ Tri lds[16];
+    const int e = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    int2 ed{0, 0};
+    if (e < ne) { ed = E[e]; t.a = tc[ed.x] > 0 || tc[ed.y] > 0; alive[e] = t.a ? 0 : 1; }
+    Tri tot;
+    Tri ex = block_exscan(t, &tot, lds);
+    if (t.a) { const int pos = bpre[blockIdx.x].a + ex.a; EH[pos] = ed; EP[pos] = e; }
+}
+// end of the chunk: the hot edges that are still there revive their old positions; (count, 0, 0) = how many
+__global__ __launch_bounds__(PB) void k_hot_revive(const int *EP, int neh, unsigned char *alive, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    const int k = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (k < neh) { const int p = EP[k]; if (p >= 0) { alive[p] = 1; t.a = 1; } }
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_alive_flags(const unsigned char *alive, int ne, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    const int e = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (e < ne) t.a = alive[e];
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_alive_emit(const int2 *E, const unsigned char *alive, int ne, const Tri *bpre, int2 *Enew)
+{
+    __shared__ Tri lds[16];
+    const int e = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (e < ne) t.a = alive[e];
+    Tri tot;
+    Tri ex = block_exscan(t, &tot, lds);
+    if (t.a) Enew[bpre[blockIdx.x].a + ex.a] = E[e];
 }
 
 // unprocessed = used && !sltn (bslv_poly.c:214-216): triple (flag, 0, 0)
@@ -1540,6 +1645,15 @@ struct bslv_poly {
     int2 *E[2] = {nullptr, nullptr};
     int ecap = 0, ne = 0, ecur = 0;
     unsigned char *eflag = nullptr;   // ecap
+    int *ecount = nullptr; int ecountcap = 0;   // per crossing edge: list length of its new vertex (k_flags2 -> k_emit2)
+    // hot mode (see PolyView): E/ecap/ne/ecur/eflag above then describe the HOT edge list and EP its positions in the
+    // full list, which waits in `full` until hot_end() merges the two
+    int *EP[2] = {nullptr, nullptr};
+    bool hot = false, hot_enabled = true;     // BSLV_NO_HOT=1 turns hot mode off
+    struct EdgeSet { int2 *E[2] = {nullptr, nullptr}; int *EP[2] = {nullptr, nullptr}; unsigned char *eflag = nullptr; int ecap = 0, ne = 0, ecur = 0; } full, hotbuf;
+    unsigned char *alive = nullptr; int alivecap = 0;     // per edge of the full list: still there at the end of the chunk
+    int *hv_d = nullptr; int hvcap = 0;                   // hot elements
+    long hot_chunks = 0, hot_elems = 0, hot_edges = 0;
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
     Tri *totals = nullptr;            // device, 4 entries
@@ -1664,6 +1778,10 @@ static int ensure_ecap(bslv_poly *h, int need)
     if ((rc = grow(&h->E[h->ecur], h->ne, ncap, h->stream))) return rc;
     if ((rc = grow(&h->E[1 - h->ecur], 0, ncap, h->stream))) return rc;
     if ((rc = grow(&h->eflag, 0, ncap, h->stream))) return rc;
+    if (h->hot) {
+        if ((rc = grow(&h->EP[h->ecur], h->ne, ncap, h->stream))) return rc;
+        if ((rc = grow(&h->EP[1 - h->ecur], 0, ncap, h->stream))) return rc;
+    }
     h->ecap = ncap;
     return 0;
 }
@@ -1769,7 +1887,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     if (tp.a > 0) {
         if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
         hipLaunchKernelGGL(k_pair_emit, dim3((unsigned)nbp), dim3(PB), 0, s, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum,
-                           h->E[h->ecur], h->ne);
+                           h->E[h->ecur], h->ne, h->EP[h->ecur]);
         HIP_TRY(hipGetLastError());
         h->ne += tp.a;
     }
@@ -1860,7 +1978,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
     int cut_id = classified ? h->pre_seq : (int)h->cutseq;       // unique per classification: stamp of the ZMarks rows
     h->pre_f = -1;
     if (cslot < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-    const int nbv = (nv0 + PB - 1) / PB;
+    const int nbv = (vm_count(h->P, nv0) + PB - 1) / PB;      // hot mode: only the elements the chunk can touch
     const int rank = (int)h->facet_of_rank.size();
     int nbe, seqB = 0, slotB = 0, spec_ns = -1;
     Tri *ebsum, *vbsum;
@@ -1873,29 +1991,31 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         ebsum = h->bsum; vbsum = h->bsum + nbe + 1;
         // room for the survivors + crossing edges (<= ne) and every pair of a small facet (k2_fused emits in place)
         if ((rc = ensure_ecap(h, ne_ub + K2_MAXNM * (K2_MAXNM - 1) / 2 + 1))) return rc;
+        if (h->ecap > h->ecountcap) { if ((rc = grow(&h->ecount, 0, (size_t)h->ecap, s))) return rc; h->ecountcap = h->ecap; }
         // ---- round A ----
         const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
         CutDev *cd = h->cutdev + cslot;
         if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters, h->zlist + ZMAX * cslot, (const int *)nullptr);
-        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, ebsum, vbsum, Z, h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
+        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, h->ecount, ebsum, vbsum, Z, h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
         const int seqA = ++h->mailseq;
         hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA,
                            cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap);
         if (spec) {
             // ---- round B, queued on the device's own verdict ----
-            launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne_ub, ne_dev, nbe, (const unsigned char *)h->eflag, (const Tri *)ebsum, (const Tri *)vbsum,
-                         (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, h->poolused, 0u, h->members, Z, (const int *)counters, (const CutDev *)cd);
+            launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne_ub, ne_dev, nbe, (const unsigned char *)h->eflag, (const int *)h->ecount, (const Tri *)ebsum, (const Tri *)vbsum,
+                         (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, h->poolused, 0u, h->members, Z, (const int *)counters, (const CutDev *)cd,
+                         (const int *)h->EP[h->ecur], h->EP[1 - h->ecur]);
             spec_ns = -1;
             if (next_f >= 0) {
                 if ((spec_ns = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-                hipLaunchKernelGGL(k_classify, dim3((nv0 + CROSS_UB + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, 0, h->counters + 4 * spec_ns, h->zlist + ZMAX * spec_ns,
+                hipLaunchKernelGGL(k_classify, dim3((vm_count(h->P, nv0) + CROSS_UB + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, 0, h->counters + 4 * spec_ns, h->zlist + ZMAX * spec_ns,
                                    (const int *)&cd->nv_new);
                 h->pre_seq = (int)h->cutseq;
             }
             seqB = ++h->mailseq;
             slotB = 2 + (h->k2flip ^= 1);
             hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
-                               h->ne_dev, h->totals + 2, h->mail_d + slotB, seqB, h->k2dbg, (const CutDev *)cd, h->abort_d);
+                               h->ne_dev, h->totals + 2, h->mail_d + slotB, seqB, h->k2dbg, (const CutDev *)cd, h->abort_d, h->EP[1 - h->ecur]);
         }
         HIP_TRY(hipGetLastError());
         if ((rc = wait_mail(h, 0, seqA))) return rc;
@@ -1947,8 +2067,9 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         // ---- round B with host arguments (no speculation, or a capacity was short and the device declined) ----
         if ((rc = ensure_vcap(h, nv0 + ncross))) return rc;
         if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
-        launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne0, (const int *)nullptr, nbe, (const unsigned char *)h->eflag, (const Tri *)ebsum, (const Tri *)vbsum,
-                     (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, pool_e, pool_z, h->members, Z, counters, (const CutDev *)nullptr);
+        launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne0, (const int *)nullptr, nbe, (const unsigned char *)h->eflag, (const int *)h->ecount, (const Tri *)ebsum, (const Tri *)vbsum,
+                     (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, pool_e, pool_z, h->members, Z, counters, (const CutDev *)nullptr,
+                     (const int *)h->EP[h->ecur], h->EP[1 - h->ecur]);
     }
     h->poolused += (unsigned)te.c + (unsigned)zero_ub;
     h->nv = nv0 + ncross;
@@ -1964,14 +2085,14 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             // classify the next halfspace now (the new vertices exist once k_emit2 has run; k2 does not read classes)
             const int ns = next_counter_slot(h);
             if (ns < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-            hipLaunchKernelGGL(k_classify, dim3((h->nv + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + 4 * ns, h->zlist + ZMAX * ns, (const int *)nullptr);
+            hipLaunchKernelGGL(k_classify, dim3((vm_count(h->P, h->nv) + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + 4 * ns, h->zlist + ZMAX * ns, (const int *)nullptr);
             h->pre_f = next_f; h->pre_slot = ns; h->pre_nv = h->nv; h->pre_seq = (int)h->cutseq;
         }
         if (nm >= 2) {
             if (nm <= K2_MAXNM) {
                 const int sq = ++h->mailseq, sl = 2 + (h->k2flip ^= 1);
                 hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, h->fcount, h->flocal,
-                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + sl, sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d);
+                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + sl, sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d, h->EP[h->ecur]);
                 HIP_TRY(hipGetLastError());
                 h->pend_k2 = true; h->pend_seq = sq; h->pend_slot = sl; h->pend_ebase = h->ne;
                 h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_nzero = nzero; h->pend_nv0 = nv0; h->pend_ncross = ncross;
@@ -1985,6 +2106,84 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
     HIP_TRY(hipGetLastError());
     h->cuts_applied++;
     *rc_out = 0;
+    return 0;
+}
+
+// ---- hot mode ----
+// Most of a large polyhedron lies strictly inside every halfspace of a chunk of cuts (the batched classification
+// says which elements do not: tc > 0).  hot_begin() moves the elements and edges a cut of the chunk can touch into
+// short lists; the per-cut passes then run over those and over what the chunk itself creates, instead of over the
+// whole polyhedron, and hot_end() merges the edge lists again.  Orders are preserved throughout: slot numbers and
+// the edge order stay exactly those of the one-list pipeline (and of oracle/poly_dd.c).
+static int hot_begin(bslv_poly *h, const int *tc)
+{
+    if (h->hot || h->pend_k2) { set_error("internal: hot_begin in the wrong state"); return BSLV_E_STATE; }
+    hipStream_t s = h->stream;
+    const int nv = h->nv, ne = h->ne, nbv = (nv + PB - 1) / PB, nbe = std::max(1, (ne + PB - 1) / PB);
+    int rc;
+    if ((rc = ensure_bsum(h, std::max(nbv, nbe) + 1))) return rc;
+    Tri t;
+    hipLaunchKernelGGL(k_hotv_flags, dim3(nbv), dim3(PB), 0, s, h->P, tc, nv, h->bsum);
+    if ((rc = scan_totals(h, nbv, &t))) return rc;
+    const int nhv = t.a;
+    if (nhv > h->hvcap) { int nc = std::max(nhv, std::max(4096, h->hvcap * 2)); if ((rc = grow(&h->hv_d, 0, (size_t)nc, s))) return rc; h->hvcap = nc; }
+    hipLaunchKernelGGL(k_hotv_emit, dim3(nbv), dim3(PB), 0, s, h->P, tc, nv, h->bsum, h->hv_d);
+    hipLaunchKernelGGL(k_hote_flags, dim3(nbe), dim3(PB), 0, s, (const int2 *)h->E[h->ecur], ne, tc, h->bsum);
+    if ((rc = scan_totals(h, nbe, &t))) return rc;
+    const int neh = t.a;
+    bslv_poly::EdgeSet &H = h->hotbuf;
+    const int need = neh + K2_MAXNM * (K2_MAXNM - 1) / 2 + 1;
+    if (need > H.ecap) {
+        const int nc = std::max(need, std::max(1 << 16, H.ecap * 2));
+        for (int k = 0; k < 2; k++) { if ((rc = grow(&H.E[k], 0, (size_t)nc, s))) return rc; if ((rc = grow(&H.EP[k], 0, (size_t)nc, s))) return rc; }
+        if ((rc = grow(&H.eflag, 0, (size_t)nc, s))) return rc;
+        H.ecap = nc;
+    }
+    if (ne > h->alivecap) { int nc = std::max(ne, std::max(1 << 16, h->alivecap * 2)); if ((rc = grow(&h->alive, 0, (size_t)nc, s))) return rc; h->alivecap = nc; }
+    hipLaunchKernelGGL(k_hote_emit, dim3(nbe), dim3(PB), 0, s, (const int2 *)h->E[h->ecur], ne, tc, (const Tri *)h->bsum, H.E[0], H.EP[0], h->alive);
+    HIP_TRY(hipGetLastError());
+    // the full list steps aside
+    bslv_poly::EdgeSet &F = h->full;
+    F.E[0] = h->E[0]; F.E[1] = h->E[1]; F.eflag = h->eflag; F.ecap = h->ecap; F.ne = ne; F.ecur = h->ecur;
+    h->E[0] = H.E[0]; h->E[1] = H.E[1]; h->EP[0] = H.EP[0]; h->EP[1] = H.EP[1]; h->eflag = H.eflag; h->ecap = H.ecap; h->ne = neh; h->ecur = 0;
+    h->P.hv = h->hv_d; h->P.nhv = nhv; h->P.nv_base = nv;
+    h->hot = true;
+    h->pre_f = -1;
+    h->hot_chunks++; h->hot_elems += nhv; h->hot_edges += neh;
+    if (getenv("BSLV_HOT_DEBUG")) fprintf(stderr, "hot chunk: %d of %d elements, %d of %d edges\n", nhv, nv, neh, ne);
+    return 0;
+}
+static int hot_end(bslv_poly *h)
+{
+    if (!h->hot) return 0;
+    int rc;
+    if ((rc = settle_k2(h))) return rc;
+    hipStream_t s = h->stream;
+    // the hot buffers may have grown: keep them for the next chunk
+    bslv_poly::EdgeSet &H = h->hotbuf, &F = h->full;
+    H.E[0] = h->E[0]; H.E[1] = h->E[1]; H.EP[0] = h->EP[0]; H.EP[1] = h->EP[1]; H.eflag = h->eflag; H.ecap = h->ecap;
+    const int neh = h->ne;
+    const int2 *EH = h->E[h->ecur];
+    const int *EPc = h->EP[h->ecur];
+    h->E[0] = F.E[0]; h->E[1] = F.E[1]; h->EP[0] = h->EP[1] = nullptr; h->eflag = F.eflag; h->ecap = F.ecap; h->ne = F.ne; h->ecur = F.ecur;
+    h->P.hv = nullptr; h->P.nhv = 0; h->P.nv_base = 0;
+    h->hot = false;
+    h->pre_f = -1;
+    const int ne = h->ne, nbe = std::max(1, (ne + PB - 1) / PB), nbh = std::max(1, (neh + PB - 1) / PB);
+    if ((rc = ensure_bsum(h, std::max(nbe, nbh) + 1))) return rc;
+    Tri t;
+    hipLaunchKernelGGL(k_hot_revive, dim3(nbh), dim3(PB), 0, s, EPc, neh, h->alive, h->bsum);
+    if ((rc = scan_totals(h, nbh, &t))) return rc;
+    const int nold = t.a;                          // hot edges of the old list that are still there: a prefix of EH
+    hipLaunchKernelGGL(k_alive_flags, dim3(nbe), dim3(PB), 0, s, (const unsigned char *)h->alive, ne, h->bsum);
+    if ((rc = scan_totals(h, nbe, &t))) return rc;
+    const int nalive = t.a, nnew = neh - nold;
+    if ((rc = ensure_ecap(h, nalive + nnew + 1))) return rc;
+    hipLaunchKernelGGL(k_alive_emit, dim3(nbe), dim3(PB), 0, s, (const int2 *)h->E[h->ecur], (const unsigned char *)h->alive, ne, (const Tri *)h->bsum, h->E[1 - h->ecur]);
+    HIP_TRY(hipGetLastError());
+    if (nnew > 0) HIP_TRY(hipMemcpyAsync(h->E[1 - h->ecur] + nalive, EH + nold, (size_t)nnew * sizeof(int2), hipMemcpyDeviceToDevice, s));
+    h->ecur = 1 - h->ecur;
+    h->ne = nalive + nnew;
     return 0;
 }
 
@@ -2078,6 +2277,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     }
     if (const char *cl = getenv("BSLV_CUT_LOG")) h->cutlog = fopen(cl, "w");
     if (getenv("BSLV_NO_SPEC")) h->speculate = false;
+    if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
     if (h->cutlog && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->fdbg, 0, 8192 * 16 * sizeof(unsigned long long));
     if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
@@ -2112,6 +2312,8 @@ void bslv_poly_destroy(bslv_poly *h)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
+    for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
+    fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
