@@ -14,6 +14,7 @@
 // sorted facet-id lists in one pool (inc_off/inc_len), edges as int2 pairs (ping-pong buffers).
 #include "common.h"
 #include <vector>
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 
@@ -24,6 +25,7 @@ constexpr double POLY_EPS = 1e-9;      // bslv_poly.h:47
 constexpr int PB = 256;                // threads per workgroup in the poly kernels
 constexpr unsigned char F_USED = 1, F_IDEAL = 2, F_SLTN = 4;
 constexpr int CRING = 1024;            // ring of per-cut classify counters
+constexpr int CSTRIDE = 8;             // ints per ring slot: #MINUS, #ZERO, list bound of the ZERO elements, #long ZERO elements, ticket of k_flags2
 constexpr int LCAP = 16;
 constexpr int LONGN = 64;      // lists longer than this are processed by a whole wave
 constexpr int ZMAX = 8;        // on-plane elements with long lists that get a facet-stamp row per cut (see ZMarks)
@@ -133,10 +135,9 @@ __device__ __forceinline__ int zmarks_find(const ZMarks &Z, const int *counters,
     for (int k = 0; k < nz; k++) if (Z.zlist[k] == v) return k;
     return -1;
 }
-__global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters, int *zlist, const int *nv_dev = nullptr)
+// classification of element number idx of the (hot) element map; whole waves call it
+__device__ __forceinline__ void classify_body(const PolyView &P, const Hp &hp, int nv, int *counters, int *zlist, int idx)
 {
-    if (nv_dev) nv = *nv_dev;          // queued before the host knew how many elements the previous cut adds
-    const int idx = blockIdx.x * PB + threadIdx.x;
     int isminus = 0, iszero = 0, zlen = 0;
     if (idx < vm_count(P, nv)) {
         const int i = vm_id(P, idx);
@@ -158,6 +159,11 @@ __global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int 
         if (bm) atomicAdd(&counters[0], __popcll(bm));
         if (bz) { atomicAdd(&counters[1], __popcll(bz)); atomicAdd(&counters[2], zlen); }
     }
+}
+__global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int *counters, int *zlist, const int *nv_dev = nullptr)
+{
+    if (nv_dev) nv = *nv_dev;          // queued before the host knew how many elements the previous cut adds
+    classify_body(P, hp, nv, counters, zlist, blockIdx.x * PB + threadIdx.x);
 }
 
 // Batched incidence kernel: classes of nv elements against B halfspaces, 2 bits
@@ -298,10 +304,16 @@ __device__ __forceinline__ int isect3_count(const int *a, int na, const int *b, 
 // Short lists (the common case: a vertex of a simple polytope lies on d facets) are fetched with 16
 // independent predicated loads -- ONE memory latency instead of a dependent chain of loads through the
 // merge loop -- and intersected in registers.  Longer lists take the merge loop.
+// The loads are unconditional (the pool is allocated with LCAP entries of slack behind its capacity, so reading
+// past the end of a list never leaves the allocation) and masked afterwards: predicated loads compiled to one
+// exec-masked load + wait per entry, i.e. 16 memory latencies in a row instead of one.
 __device__ __forceinline__ void load_list(const int *p, int n, int (&out)[LCAP])
 {
+    int raw[LCAP];
 #pragma unroll
-    for (int k = 0; k < LCAP; k++) out[k] = k < n ? p[k] : 0x7FFFFFFF;
+    for (int k = 0; k < LCAP; k++) raw[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < LCAP; k++) out[k] = k < n ? raw[k] : 0x7FFFFFFF;
 }
 // bit a of the result: A[a] occurs in B (both sorted, padded with INT_MAX which never matches a < n entry)
 __device__ __forceinline__ unsigned match_mask(const int (&A)[LCAP], int na, const int (&B)[LCAP])
@@ -920,6 +932,68 @@ __device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed, cons
     }
 }
 
+// What the host decides after round A, decided on the device as well, so that round B can be queued before the
+// host has seen the result (speculative launch): go = the cut removes something, every capacity suffices and the
+// adjacency prune of the previous cut did not ask for its fallback (abort flag).
+constexpr int CROSS_UB = 4096;         // new vertices a speculatively queued classification of the next cut covers
+struct CutDev { int go, nminus, nzero, zero_ub, nsurv, ncross, newlen, ne0, nv_new, ebase; unsigned pool_z; int pad; };
+// both scans in one launch: workgroup 0 the edge sums (-> totals[0], mail[0] with the classify counters and,
+// in cnt[3], the exact edge count this cut saw), workgroup 1 the vertex sums (-> totals[1])
+struct ScanArgs {
+    Tri *ebsum; int nbe; Tri *vbsum; int nbv; Tri *totals; Mail *mail; const int *counters; int ne_ub; const int *ne_dev; int seq;
+    CutDev *cd; const int *abort_flag; int nv0, vcap; unsigned poolused, poolcap;
+};
+// scan of one array of block sums by the calling workgroup (any size): sums[] becomes exclusive prefixes
+__device__ __forceinline__ Tri scan_sums(Tri *sums, int nb, Tri *lds)
+{
+    Tri carry{0, 0, 0};
+    for (int base = 0; base < nb; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const Tri v = i < nb ? sums[i] : Tri{0, 0, 0};
+        Tri tot;
+        Tri ex = block_exscan(v, &tot, lds);
+        if (i < nb) sums[i] = tri_add(ex, carry);
+        carry = tri_add(carry, tot);
+        __syncthreads();
+    }
+    return carry;
+}
+// totals, the device's verdict (CutDev) and the host mailbox of round A; called by one thread
+__device__ __forceinline__ void publish_round_a(const ScanArgs &A, Tri te)
+{
+    A.totals[0] = te;
+    const int ne0 = A.ne_dev ? *A.ne_dev : A.ne_ub;
+    if (A.cd) {
+        CutDev c;
+        c.nminus = A.counters[0]; c.nzero = A.counters[1]; c.zero_ub = A.counters[2];
+        c.nsurv = te.a; c.ncross = te.b; c.newlen = te.c; c.ne0 = ne0;
+        c.go = c.nminus > 0 && !*A.abort_flag && c.ncross <= CROSS_UB && A.nv0 + c.ncross <= A.vcap &&
+               (unsigned long long)A.poolused + (unsigned)c.newlen + (unsigned)c.zero_ub <= A.poolcap;
+        c.nv_new = c.go ? A.nv0 + c.ncross : A.nv0;
+        c.ebase = c.go ? c.nsurv + c.ncross : ne0;
+        c.pool_z = A.poolused + (unsigned)c.newlen;
+        c.pad = 0;
+        *A.cd = c;
+    }
+    A.mail->t = te;
+    for (int k = 0; k < 3; k++) A.mail->cnt[k] = A.counters[k];
+    A.mail->cnt[3] = ne0;
+    __threadfence_system();
+    A.mail->seq = A.seq;
+}
+// both scans of round A in one launch
+__global__ __launch_bounds__(1024) void k_scan2(ScanArgs A)
+{
+    __shared__ Tri lds[16];
+    if (blockIdx.x == 0) {             // the edge sums carry everything the verdict needs
+        const Tri te = scan_sums(A.ebsum, A.nbe, lds);
+        if (threadIdx.x == 0) publish_round_a(A, te);
+    } else {
+        const Tri tv = scan_sums(A.vbsum, A.nbv, lds);
+        if (threadIdx.x == 0) A.totals[1] = tv;
+    }
+}
+
 // flags pass.  Edge blocks: eflag + (survive, cross, new list length) sums, and -- once the cut is known to
 // remove something (counters[0] = #MINUS, final since k_classify) -- the keep marks of ZERO-PLUS edges.
 // Vertex blocks: (is ZERO, 0, old list length + 1): the rebuilt list of an on-plane element is allocated at
@@ -932,15 +1006,15 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
     __shared__ Tri lds[16];
     Tri t{0, 0, 0};
     Tri tot;
-    __shared__ unsigned s_dbg[2];
-    if (dbg && threadIdx.x == 0) { s_dbg[0] = 0; s_dbg[1] = 0; }
+    __shared__ unsigned s_dbg[4];
+    if (dbg && threadIdx.x == 0) { s_dbg[0] = 0; s_dbg[1] = 0; s_dbg[2] = 0; s_dbg[3] = 0; }
     const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
     struct Fin { unsigned long long *dbg, t0; unsigned *sd; __device__ ~Fin() {
-        if (dbg && threadIdx.x == 0) {       // profiling aid: slowest block, slowest crossing / marking lane (100 MHz ticks)
-            const unsigned long long dt = wall_clock64() - t0;
-            if (dt > 500) atomicMax(&dbg[0], (dt << 32) | blockIdx.x);
-            if (sd[0] > 300) atomicMax(&dbg[10], (unsigned long long)sd[0]);
-            if (sd[1] > 300) atomicMax(&dbg[11], (unsigned long long)sd[1]);
+        if (dbg && threadIdx.x == 0) {       // profiling aid (100 MHz ticks): slowest block; per-level latency of the slowest lane; first start / last end
+            const unsigned long long t1 = wall_clock64(), dt = t1 - t0;
+            atomicMax(&dbg[0], (dt << 32) | blockIdx.x);
+            for (int k = 0; k < 4; k++) atomicMax(&dbg[3 + k], (unsigned long long)sd[k]);
+            atomicMin(&dbg[12], t0); atomicMax(&dbg[13], t1);
         } } } fin{dbg, t_start, s_dbg};
     // blocks run back to front: the edges and elements the recent cuts created -- where the next cut acts, with the
     // long dependent chains -- sit at the end of the arrays and must not wait for a second wave of workgroups
@@ -951,6 +1025,8 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
         if (e < ne) {
             const int2 ed = E[e];
             const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
+            unsigned long long tq1 = 0, tq2 = 0, tq3 = 0;
+            if (dbg && (ca + cb < 2)) tq1 = wall_clock64();
             unsigned char f = 0;
             if ((ca == -1 && cb == 1) || (ca == 1 && cb == -1)) { f = (ca == -1) ? 2 : 3; t.b = 1; }
             else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = (ca == 0 || cb == 0) ? 4 : 1; t.a = 1; }
@@ -962,10 +1038,12 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
                 // code path, so that a wave holding edges of both kinds does not walk two chains one after the other
                 const int ia = (mark && ca != 0) ? ed.y : ed.x, ib = ia == ed.x ? ed.y : ed.x;      // A = the ZERO element of a marking edge
                 const int na = P.inc_len[ia], nb = P.inc_len[ib];
+                if (dbg && na + nb > 0) tq2 = wall_clock64();
                 if (na <= LCAP && nb <= LCAP) {
                     int RA[LCAP], RB[LCAP];
                     load_list(P.pool + P.inc_off[ia], na, RA); load_list(P.pool + P.inc_off[ib], nb, RB);
                     unsigned m = match_mask(RA, na, RB);
+                    if (dbg && m + 1 > 0) tq3 = wall_clock64();
                     if (cross) t.c = __popc(m) + 1;
                     else {
                         unsigned char *K = P.keep + P.inc_off[ia];
@@ -974,6 +1052,11 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
                 } else if (cross) t.c = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
                 else mark_keep(P, ed, Z, counters);
                 if (cross) ecount[e] = t.c;
+                if (dbg && tq3) {
+                    const unsigned long long tq4 = wall_clock64();
+                    atomicMax(&s_dbg[0], (unsigned)(tq1 - t_start)); atomicMax(&s_dbg[1], (unsigned)(tq2 - tq1));
+                    atomicMax(&s_dbg[2], (unsigned)(tq3 - tq2)); atomicMax(&s_dbg[3], (unsigned)(tq4 - tq3));
+                }
             }
         }
         (void)block_exscan(t, &tot, lds);
@@ -985,55 +1068,6 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
         if (threadIdx.x == 0) vbsum[b] = tot;
     }
 }
-// What the host decides after round A, decided on the device as well, so that round B can be queued before the
-// host has seen the result (speculative launch): go = the cut removes something, every capacity suffices and the
-// adjacency prune of the previous cut did not ask for its fallback (abort flag).
-constexpr int CROSS_UB = 4096;         // new vertices a speculatively queued classification of the next cut covers
-struct CutDev { int go, nminus, nzero, zero_ub, nsurv, ncross, newlen, ne0, nv_new, ebase; unsigned pool_z; int pad; };
-// both scans in one launch: workgroup 0 the edge sums (-> totals[0], mail[0] with the classify counters and,
-// in cnt[3], the exact edge count this cut saw), workgroup 1 the vertex sums (-> totals[1])
-__global__ __launch_bounds__(1024) void k_scan2(Tri *ebsum, int nbe, Tri *vbsum, int nbv, Tri *totals, Mail *mail, const int *counters,
-                                                int ne_ub, const int *ne_dev, int seq, CutDev *cd, const int *abort_flag, int nv0, int vcap,
-                                                unsigned poolused, unsigned poolcap)
-{
-    __shared__ Tri lds[16];
-    Tri *sums = blockIdx.x == 0 ? ebsum : vbsum;
-    const int nb = blockIdx.x == 0 ? nbe : nbv;
-    Tri carry{0, 0, 0};
-    for (int base = 0; base < nb; base += 1024) {
-        int i = base + threadIdx.x;
-        Tri v = i < nb ? sums[i] : Tri{0, 0, 0};
-        Tri tot;
-        Tri ex = block_exscan(v, &tot, lds);
-        if (i < nb) sums[i] = tri_add(ex, carry);
-        carry = tri_add(carry, tot);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        totals[blockIdx.x] = carry;
-        if (blockIdx.x == 0) {
-            const int ne0 = ne_dev ? *ne_dev : ne_ub;
-            if (cd) {
-                CutDev c;
-                c.nminus = counters[0]; c.nzero = counters[1]; c.zero_ub = counters[2];
-                c.nsurv = carry.a; c.ncross = carry.b; c.newlen = carry.c; c.ne0 = ne0;
-                c.go = c.nminus > 0 && !*abort_flag && c.ncross <= CROSS_UB && nv0 + c.ncross <= vcap &&
-                       (unsigned long long)poolused + (unsigned)c.newlen + (unsigned)c.zero_ub <= poolcap;
-                c.nv_new = c.go ? nv0 + c.ncross : nv0;
-                c.ebase = c.go ? c.nsurv + c.ncross : ne0;
-                c.pool_z = poolused + (unsigned)c.newlen;
-                c.pad = 0;
-                *cd = c;
-            }
-            mail->t = carry;
-            for (int k = 0; k < 3; k++) mail->cnt[k] = counters[k];
-            mail->cnt[3] = ne0;
-            __threadfence_system();
-            mail->seq = seq;
-        }
-    }
-}
-
 // emit pass.  Edge blocks: survivors -> Enew[0..nsurv), one new vertex per crossing edge (coordinates, flags,
 // incidence list, its edge to the PLUS end at Enew[nsurv + crossidx]).  Vertex blocks: MINUS elements leave,
 // ZERO elements get their kept facets + the new one at pool[pool_z + prefix) and become members[0..nzero).
@@ -1298,9 +1332,15 @@ __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const uns
 }
 __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
                                                 int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg,
-                                                const CutDev *cd, int *abort_flag, int *EP)
+                                                const CutDev *cd, int *abort_flag, int *EP, Hp hn, int *counters_n, int *zlist_n)
 {
     extern __shared__ unsigned long long k2_dyn[];
+    if (blockIdx.x > 0) {
+        // workgroups 1.. ride along: they classify the elements against the NEXT halfspace (the prune reads no
+        // classes), which saves that launch
+        classify_body(P, hn, cd->nv_new, counters_n, zlist_n, (blockIdx.x - 1) * K2T + threadIdx.x);
+        return;
+    }
     if (cd) {                          // speculative launch: sizes from the device, nothing to do unless the cut goes ahead
         nzero = cd->nzero; ncross = cd->ncross; ebase = cd->ebase;
         const int nm_ = nzero + ncross;
@@ -1654,6 +1694,7 @@ struct bslv_poly {
     unsigned char *alive = nullptr; int alivecap = 0;     // per edge of the full list: still there at the end of the chunk
     int *hv_d = nullptr; int hvcap = 0;                   // hot elements
     long hot_chunks = 0, hot_elems = 0, hot_edges = 0;
+    double tm_hot_begin = 0, tm_seq = 0, tm_hot_end = 0, tm_add_cuts = 0; long tm_seq_cuts = 0;   // host wall clock (ms), printed at destroy with BSLV_TIMING
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
     Tri *totals = nullptr;            // device, 4 entries
@@ -1765,7 +1806,7 @@ static int ensure_pool(bslv_poly *h, size_t need)
     if (need > 0xF0000000ull) { set_error("incidence pool exceeds 32-bit offsets"); return BSLV_E_CAPACITY; }
     size_t ncap = std::min<size_t>(0xF0000000ull, std::max(need, std::max<size_t>(1 << 16, (size_t)h->poolcap * 2)));
     int rc;
-    if ((rc = grow(&h->P.pool, h->poolused, ncap, h->stream))) return rc;
+    if ((rc = grow(&h->P.pool, h->poolused, ncap + 64, h->stream))) return rc;      // + slack for load_list
     if ((rc = grow(&h->P.keep, h->poolused, ncap, h->stream, true))) return rc;
     h->poolcap = (unsigned)ncap;
     return 0;
@@ -1920,7 +1961,7 @@ static int settle_k2(bslv_poly *h, bool *redo = nullptr)
 static int next_counter_slot(bslv_poly *h)
 {
     const int cslot = (int)(h->cutseq % CRING);
-    if (cslot == 0 && h->cutseq > 0 && hipMemsetAsync(h->counters, 0, CRING * 4 * sizeof(int), h->stream) != hipSuccess) return -1;
+    if (cslot == 0 && h->cutseq > 0 && hipMemsetAsync(h->counters, 0, CRING * CSTRIDE * sizeof(int), h->stream) != hipSuccess) return -1;
     h->cutseq++;
     return cslot;
 }
@@ -1983,7 +2024,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
     int nbe, seqB = 0, slotB = 0, spec_ns = -1;
     Tri *ebsum, *vbsum;
     for (;;) {
-        int *counters = h->counters + 4 * cslot;
+        int *counters = h->counters + CSTRIDE * cslot;
         const int ne_ub = h->ne;                   // exact unless a prune is in flight
         const int *ne_dev = h->pend_k2 ? h->ne_dev : nullptr;
         nbe = std::max(1, (ne_ub + PB - 1) / PB);
@@ -1996,26 +2037,30 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
         CutDev *cd = h->cutdev + cslot;
         if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters, h->zlist + ZMAX * cslot, (const int *)nullptr);
-        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, h->ecount, ebsum, vbsum, Z, h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
         const int seqA = ++h->mailseq;
-        hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA,
-                           cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap);
+        const ScanArgs SA{ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA, cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap};
+        // (letting the last workgroup of k_flags2 do the scans -- ticket + fences -- was measured SLOWER than this
+        // second launch: an agent-scope fence per workgroup writes the L2 back)
+        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, h->ecount, ebsum, vbsum, Z,
+                           h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
+        hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, SA);
         if (spec) {
             // ---- round B, queued on the device's own verdict ----
             launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne_ub, ne_dev, nbe, (const unsigned char *)h->eflag, (const int *)h->ecount, (const Tri *)ebsum, (const Tri *)vbsum,
                          (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, h->poolused, 0u, h->members, Z, (const int *)counters, (const CutDev *)cd,
                          (const int *)h->EP[h->ecur], h->EP[1 - h->ecur]);
             spec_ns = -1;
+            int ncb = 0;                       // workgroups of the prune launch that classify the next halfspace
             if (next_f >= 0) {
                 if ((spec_ns = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-                hipLaunchKernelGGL(k_classify, dim3((vm_count(h->P, nv0) + CROSS_UB + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, 0, h->counters + 4 * spec_ns, h->zlist + ZMAX * spec_ns,
-                                   (const int *)&cd->nv_new);
+                ncb = (vm_count(h->P, nv0) + CROSS_UB + K2T - 1) / K2T;
                 h->pre_seq = (int)h->cutseq;
             }
             seqB = ++h->mailseq;
             slotB = 2 + (h->k2flip ^= 1);
-            hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
-                               h->ne_dev, h->totals + 2, h->mail_d + slotB, seqB, h->k2dbg, (const CutDev *)cd, h->abort_d, h->EP[1 - h->ecur]);
+            hipLaunchKernelGGL(k2_fused, dim3(1 + ncb), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
+                               h->ne_dev, h->totals + 2, h->mail_d + slotB, seqB, h->k2dbg, (const CutDev *)cd, h->abort_d, h->EP[1 - h->ecur],
+                               hn, h->counters + CSTRIDE * std::max(spec_ns, 0), h->zlist + ZMAX * std::max(spec_ns, 0));
         }
         HIP_TRY(hipGetLastError());
         if ((rc = wait_mail(h, 0, seqA))) return rc;
@@ -2044,7 +2089,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         cut_id = (int)h->cutseq;
     }
     const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
-    const int *counters = h->counters + 4 * cslot;
+    const int *counters = h->counters + CSTRIDE * cslot;
     const int nminus = h->mail_h[0].cnt[0], nzero = h->mail_h[0].cnt[1], zero_ub = h->mail_h[0].cnt[2];
     const Tri te = h->mail_h[0].t;
     const int ne0 = h->ne;
@@ -2085,14 +2130,14 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             // classify the next halfspace now (the new vertices exist once k_emit2 has run; k2 does not read classes)
             const int ns = next_counter_slot(h);
             if (ns < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-            hipLaunchKernelGGL(k_classify, dim3((vm_count(h->P, h->nv) + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + 4 * ns, h->zlist + ZMAX * ns, (const int *)nullptr);
+            hipLaunchKernelGGL(k_classify, dim3((vm_count(h->P, h->nv) + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + CSTRIDE * ns, h->zlist + ZMAX * ns, (const int *)nullptr);
             h->pre_f = next_f; h->pre_slot = ns; h->pre_nv = h->nv; h->pre_seq = (int)h->cutseq;
         }
         if (nm >= 2) {
             if (nm <= K2_MAXNM) {
                 const int sq = ++h->mailseq, sl = 2 + (h->k2flip ^= 1);
                 hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, h->fcount, h->flocal,
-                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + sl, sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d, h->EP[h->ecur]);
+                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + sl, sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d, h->EP[h->ecur], hn, (int *)nullptr, (int *)nullptr);
                 HIP_TRY(hipGetLastError());
                 h->pend_k2 = true; h->pend_seq = sq; h->pend_slot = sl; h->pend_ebase = h->ne;
                 h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_nzero = nzero; h->pend_nv0 = nv0; h->pend_ncross = ncross;
@@ -2260,12 +2305,12 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     h->P.d = dim;
     auto fail = [&](int code) { bslv_poly_destroy(h); return code; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
-    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->cutdev, CRING * sizeof(CutDev)) != hipSuccess ||
+    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * CSTRIDE * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->cutdev, CRING * sizeof(CutDev)) != hipSuccess ||
         hipMalloc(&h->abort_d, 4 * sizeof(int)) != hipSuccess || hipMemset(h->abort_d, 0, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->zlist, CRING * ZMAX * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->mail_h, 4 * sizeof(Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&h->mail_d, h->mail_h, 0) != hipSuccess ||
-        hipMemset(h->counters, 0, CRING * 4 * sizeof(int)) != hipSuccess) {
+        hipMemset(h->counters, 0, CRING * CSTRIDE * sizeof(int)) != hipSuccess) {
         set_error("allocation of scan scratch failed");
         return fail(BSLV_E_NOMEM);
     }
@@ -2278,7 +2323,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (const char *cl = getenv("BSLV_CUT_LOG")) h->cutlog = fopen(cl, "w");
     if (getenv("BSLV_NO_SPEC")) h->speculate = false;
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
-    if (h->cutlog && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->fdbg, 0, 8192 * 16 * sizeof(unsigned long long));
+    if (h->cutlog && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) { std::vector<unsigned long long> z(8192 * 16, 0ull); for (int k = 0; k < 8192; k++) z[16 * k + 12] = ~0ull; (void)hipMemcpy(h->fdbg, z.data(), z.size() * 8, hipMemcpyHostToDevice); }
     if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
     // dual slot 0: "facet at infinity", ideal point (0,..,0,-1)  (bslv_poly.c:83-92)
@@ -2292,13 +2337,18 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
 void bslv_poly_destroy(bslv_poly *h)
 {
     if (!h) return;
+    if (getenv("BSLV_TIMING"))
+        fprintf(stderr, "poly timing: add_cuts %.1f ms | hot_begin %.1f, sequences %.1f (%ld cuts, %.1f us each), hot_end %.1f ms | %ld hot chunks, %.0f elements, %.0f edges on average\n", h->tm_add_cuts,
+                h->tm_hot_begin, h->tm_seq, h->tm_seq_cuts, h->tm_seq_cuts ? h->tm_seq * 1e3 / h->tm_seq_cuts : 0.0, h->tm_hot_end, h->hot_chunks,
+                h->hot_chunks ? (double)h->hot_elems / h->hot_chunks : 0.0, h->hot_chunks ? (double)h->hot_edges / h->hot_chunks : 0.0);
     if (h->cutlog && h->fdbg) {
         std::vector<unsigned long long> t(8192 * 16);
         if (hipMemcpy(t.data(), h->fdbg, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             for (long k = 0; k < std::min<long>(h->nflagslaunch, 8192); k++)
                 { fprintf(h->cutlog, "F %ld %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", k, t[16 * k] >> 32, t[16 * k] & 0xffffffffull, t[16 * k + 1], t[16 * k + 2],
                         t[16 * k + 3], t[16 * k + 4], t[16 * k + 5], t[16 * k + 6], t[16 * k + 7], t[16 * k + 8], t[16 * k + 9]);
-                fprintf(h->cutlog, "G %ld %llu %llu\n", k, t[16 * k + 10], t[16 * k + 11]); }
+                fprintf(h->cutlog, "G %ld %llu %llu\n", k, t[16 * k + 10], t[16 * k + 11]);
+                  fprintf(h->cutlog, "H %ld %llu\n", k, t[16 * k + 13] - t[16 * k + 12]); }
         (void)hipFree(h->fdbg);
     }
     if (h->cutlog) fclose(h->cutlog);
@@ -2421,7 +2471,12 @@ int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal,
     const int d = h->d;
     std::vector<int> fids(B);
     for (int b = 0; b < B; b++) fids[b] = new_dual(h, val + (size_t)b * d, ideal ? ideal[b] : 0);
-    if (h->batch_mode == 1 && B >= 2) return apply_cuts_rounds(h, fids, rc_out);
+    if (h->batch_mode == 1 && B >= 2) {
+        auto t0 = std::chrono::steady_clock::now();
+        int rc = apply_cuts_rounds(h, fids, rc_out);
+        h->tm_add_cuts += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    }
     std::vector<int> anym(B, 1);
     if (B >= 2) {
         int rc;
