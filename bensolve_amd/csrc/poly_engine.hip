@@ -935,13 +935,13 @@ __device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed, cons
 // What the host decides after round A, decided on the device as well, so that round B can be queued before the
 // host has seen the result (speculative launch): go = the cut removes something, every capacity suffices and the
 // adjacency prune of the previous cut did not ask for its fallback (abort flag).
-constexpr int CROSS_UB = 4096;         // new vertices a speculatively queued classification of the next cut covers
+constexpr int CROSS_UB = 4096;         // new vertices a speculatively queued classification of the next cut covers (default of bslv_poly::cross_ub)
 struct CutDev { int go, nminus, nzero, zero_ub, nsurv, ncross, newlen, ne0, nv_new, ebase; unsigned pool_z; int pad; };
 // both scans in one launch: workgroup 0 the edge sums (-> totals[0], mail[0] with the classify counters and,
 // in cnt[3], the exact edge count this cut saw), workgroup 1 the vertex sums (-> totals[1])
 struct ScanArgs {
     Tri *ebsum; int nbe; Tri *vbsum; int nbv; Tri *totals; Mail *mail; const int *counters; int ne_ub; const int *ne_dev; int seq;
-    CutDev *cd; const int *abort_flag; int nv0, vcap; unsigned poolused, poolcap;
+    CutDev *cd; const int *abort_flag; int nv0, vcap; unsigned poolused, poolcap; int cross_ub;
 };
 // scan of one array of block sums by the calling workgroup (any size): sums[] becomes exclusive prefixes
 __device__ __forceinline__ Tri scan_sums(Tri *sums, int nb, Tri *lds)
@@ -967,7 +967,7 @@ __device__ __forceinline__ void publish_round_a(const ScanArgs &A, Tri te)
         CutDev c;
         c.nminus = A.counters[0]; c.nzero = A.counters[1]; c.zero_ub = A.counters[2];
         c.nsurv = te.a; c.ncross = te.b; c.newlen = te.c; c.ne0 = ne0;
-        c.go = c.nminus > 0 && !*A.abort_flag && c.ncross <= CROSS_UB && A.nv0 + c.ncross <= A.vcap &&
+        c.go = c.nminus > 0 && !*A.abort_flag && c.ncross <= A.cross_ub && A.nv0 + c.ncross <= A.vcap &&
                (unsigned long long)A.poolused + (unsigned)c.newlen + (unsigned)c.zero_ub <= A.poolcap;
         c.nv_new = c.go ? A.nv0 + c.ncross : A.nv0;
         c.ebase = c.go ? c.nsurv + c.ncross : ne0;
@@ -1372,6 +1372,10 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     unsigned *adj_bits = (unsigned *)k2_dyn;
     unsigned long long *bits = k2_dyn + (nadjw + 1) / 2;
     const long long bits_cap = (long long)lds_words - (nadjw + 1) / 2;
+    if (bits_cap < 0) {                 // not even the pair bitmap fits (uniform): multi-kernel prune
+        if (threadIdx.x == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; __threadfence_system(); mail->seq = seq; }
+        return;
+    }
     // P0: members (ZERO elements from k_emit2, then the new vertices), their lists
     for (int m = tid; m < nm; m += K2T) {
         int v;
@@ -1694,6 +1698,7 @@ struct bslv_poly {
     unsigned char *alive = nullptr; int alivecap = 0;     // per edge of the full list: still there at the end of the chunk
     int *hv_d = nullptr; int hvcap = 0;                   // hot elements
     long hot_chunks = 0, hot_elems = 0, hot_edges = 0;
+    long n_spec = 0, n_declined = 0, n_k2_fallback = 0, n_single = 0;     // bslv_poly_path_stats
     double tm_hot_begin = 0, tm_seq = 0, tm_hot_end = 0, tm_add_cuts = 0; long tm_seq_cuts = 0;   // host wall clock (ms), printed at destroy with BSLV_TIMING
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
@@ -1711,6 +1716,7 @@ struct bslv_poly {
     int pend_seq = 0, pend_slot = 2, pend_ebase = 0, pend_nm = 0, pend_stamp = 0, pend_nzero = 0, pend_nv0 = 0, pend_ncross = 0; long long pend_len_ub = 0;
     int k2flip = 0;                   // the prune mailbox alternates between two slots: one result may wait while the next is queued
     bool speculate = true;            // queue round B before the host has seen round A (BSLV_NO_SPEC=1 turns it off)
+    int cross_ub = CROSS_UB;          // (BSLV_CROSS_UB=n: test hook, small values force the decline-and-rerun path)
     CutDev *cutdev = nullptr;         // CRING verdicts of k_scan2
     int *abort_d = nullptr;           // set by a k2_fused that needs its fallback: everything queued behind it declines
     int *fcount = nullptr;            // per facet rank: member lists it occurs in (k2_fused; zero between cuts)
@@ -1949,6 +1955,7 @@ static int settle_k2(bslv_poly *h, bool *redo = nullptr)
     const Tri tp = h->mail_h[h->pend_slot].t;
     h->ne = h->pend_ebase;
     if (tp.b == 1) {
+        h->n_k2_fallback++;
         if (redo) *redo = true;
         HIP_TRY(hipMemsetAsync(h->abort_d, 0, sizeof(int), h->stream));
         if (h->pend_ncross > 0)
@@ -2011,8 +2018,8 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
     }
     bool spec = h->speculate;
     if (spec) {   // head-room that lets the device say yes: CROSS_UB new elements with their lists
-        if ((rc = ensure_vcap(h, nv0 + CROSS_UB))) return rc;
-        if ((rc = ensure_pool(h, (size_t)h->poolused + (size_t)CROSS_UB * 64))) return rc;
+        if ((rc = ensure_vcap(h, nv0 + h->cross_ub))) return rc;
+        if ((rc = ensure_pool(h, (size_t)h->poolused + (size_t)h->cross_ub * 64))) return rc;
     }
     bool classified = h->pre_f == f && h->pre_nv == nv0;
     int cslot = classified ? h->pre_slot : next_counter_slot(h);
@@ -2038,7 +2045,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         CutDev *cd = h->cutdev + cslot;
         if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters, h->zlist + ZMAX * cslot, (const int *)nullptr);
         const int seqA = ++h->mailseq;
-        const ScanArgs SA{ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA, cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap};
+        const ScanArgs SA{ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA, cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap, h->cross_ub};
         // (letting the last workgroup of k_flags2 do the scans -- ticket + fences -- was measured SLOWER than this
         // second launch: an agent-scope fence per workgroup writes the L2 back)
         hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, h->ecount, ebsum, vbsum, Z,
@@ -2053,7 +2060,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             int ncb = 0;                       // workgroups of the prune launch that classify the next halfspace
             if (next_f >= 0) {
                 if ((spec_ns = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-                ncb = (vm_count(h->P, nv0) + CROSS_UB + K2T - 1) / K2T;
+                ncb = (vm_count(h->P, nv0) + h->cross_ub + K2T - 1) / K2T;
                 h->pre_seq = (int)h->cutseq;
             }
             seqB = ++h->mailseq;
@@ -2072,13 +2079,14 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             // without speculation
             const Tri t0 = h->mail_h[0].t;
             const int zub = h->mail_h[0].cnt[2];
-            if (!(t0.b <= CROSS_UB && nv0 + t0.b <= h->P.cap && (unsigned long long)h->poolused + (unsigned)t0.c + (unsigned)zub <= h->poolcap)) {
+            if (!(t0.b <= h->cross_ub && nv0 + t0.b <= h->P.cap && (unsigned long long)h->poolused + (unsigned)t0.c + (unsigned)zub <= h->poolcap)) {
                 h->pend_k2 = true; h->pend_seq = seqB; h->pend_slot = slotB; h->pend_ebase = h->ne; h->pend_ncross = 0;
                 if ((rc = settle_k2(h))) return rc;
                 if ((rc = ensure_vcap(h, nv0 + t0.b))) return rc;
                 if ((rc = ensure_pool(h, (size_t)h->poolused + t0.c + zub))) return rc;
                 spec = false;
                 redo = true;
+                h->n_declined++;
             }
         }
         if (!redo) break;
@@ -2098,6 +2106,8 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
     const int nsurv = te.a, ncross = te.b;
     const int nm = nzero + ncross;
     const long long len_ub = (long long)te.c + zero_ub;
+    h->n_single++;
+    if (spec) h->n_spec++;
     const bool went = spec && nminus > 0;         // (capacities were checked in the loop, with the verdict of k_scan2)
     if (spec) {   // the queued prune reports in any case (nothing to do / pairs / fallback): book it at the next wait
         h->pend_k2 = true; h->pend_seq = seqB; h->pend_slot = slotB;
@@ -2323,6 +2333,8 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (const char *cl = getenv("BSLV_CUT_LOG")) h->cutlog = fopen(cl, "w");
     if (getenv("BSLV_NO_SPEC")) h->speculate = false;
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
+    if (const char *e = getenv("BSLV_CROSS_UB")) h->cross_ub = std::max(0, atoi(e));
+    if (const char *e = getenv("BSLV_K2_LDS")) h->k2_lds = (size_t)std::max(64, atoi(e));      // test hook: a small value forces the multi-kernel prune
     if (h->cutlog && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) { std::vector<unsigned long long> z(8192 * 16, 0ull); for (int k = 0; k < 8192; k++) z[16 * k + 12] = ~0ull; (void)hipMemcpy(h->fdbg, z.data(), z.size() * 8, hipMemcpyHostToDevice); }
     if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
@@ -2633,6 +2645,12 @@ int bslv_poly_set_batch_mode(bslv_poly *h, int mode)
     return 0;
 }
 long bslv_poly_rounds_run(const bslv_poly *h) { return h ? h->rounds_run : 0; }
+int bslv_poly_path_stats(const bslv_poly *h, long out[6])
+{
+    if (!h || !out) return BSLV_E_ARG;
+    out[0] = h->hot_chunks; out[1] = h->n_spec; out[2] = h->n_declined; out[3] = h->n_k2_fallback; out[4] = h->n_single; out[5] = 0;
+    return 0;
+}
 long bslv_poly_conflict_pairs(const bslv_poly *h) { return h ? h->conf_pairs : 0; }
 // MEASUREMENT ONLY (bench / profiles): turns the engine into nv synthetic live points so that the
 // batched incidence kernel can be timed at sizes beyond the caches.  The polyhedron is destroyed.

@@ -22,6 +22,8 @@ def _bind(lib):
     lib.bslv_poly_set_batch_mode.argtypes = [vp, i]
     lib.bslv_poly_rounds_run.argtypes = [vp]
     lib.bslv_poly_rounds_run.restype = ctypes.c_long
+    lib.bslv_poly_path_stats.argtypes = [vp, vp]
+    lib.bslv_poly_path_stats.restype = ctypes.c_int
     lib.bslv_poly_next.argtypes = [vp, vp, vp, vp, vp]
     lib.bslv_poly_unprocessed.argtypes = [vp, i, vp, vp, vp, vp]
     lib.bslv_poly_mark.argtypes = [vp, i, vp]
@@ -88,6 +90,11 @@ class PolyEngine:
 
     def rounds_run(self):
         return self.lib.bslv_poly_rounds_run(self.h)
+
+    def path_stats(self):
+        out = (ctypes.c_long * 6)()
+        check(self.lib.bslv_poly_path_stats(self.h, out))
+        return dict(hot_chunks=out[0], speculative=out[1], declined=out[2], prune_fallbacks=out[3], single_cuts=out[4])
 
     def init(self):
         rc = ctypes.c_int()

@@ -110,6 +110,10 @@ int  bslv_poly_add_cuts(bslv_poly *h, int B, const double *val /* B*dim */, cons
  * 1 = rounds of independent cuts applied in one pass each (default; same sets, different slot numbers) */
 int  bslv_poly_set_batch_mode(bslv_poly *h, int mode);
 long bslv_poly_rounds_run(const bslv_poly *h);
+/* which paths of the single-cut pipeline ran (tests, tuning): out[0] chunks in hot mode, [1] cuts whose round B was
+ * queued speculatively, [2] of those declined by the device and rerun, [3] prunes redone by the multi-kernel path,
+ * [4] cuts applied one at a time, [5] reserved */
+int  bslv_poly_path_stats(const bslv_poly *h, long out[6]);
 int  bslv_poly_init(bslv_poly *h, int *rc_out);               /* poly__intl_apprx :153 */
 int  bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out); /* poly__get_vrtx :210 */
 int  bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count);

@@ -1,0 +1,122 @@
+"""Execution modes of the single-cut pipeline (speculative launch of round B, hot mode for chunks of cuts, the
+one-workgroup adjacency prune and its multi-kernel fallback, the decline-and-rerun path when the device finds a
+capacity short) must all build the SAME polyhedron, slot by slot.  The modes are forced through the engine's
+test hooks (environment variables read by bslv_poly_create) and compared bit for bit with the CPU oracle
+(oracle/poly_dd.c restates bslv_poly.c:104-330) and with each other."""
+import os
+import numpy as np
+import pytest
+
+import poly_harness as ph
+from bensolve_amd.poly import PolyEngine
+from test_poly_gpu import assert_slotwise_equal
+
+pytestmark = pytest.mark.gpu
+
+HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS"]
+MODES = {
+    "default": {},
+    "no_spec": {"BSLV_NO_SPEC": "1"},
+    "no_hot": {"BSLV_NO_HOT": "1"},
+    "no_spec_no_hot": {"BSLV_NO_SPEC": "1", "BSLV_NO_HOT": "1"},
+    "decline": {"BSLV_CROSS_UB": "3"},                 # most cuts create more than 3 vertices: round B is declined and rerun
+    "multi_kernel_prune": {"BSLV_K2_LDS": "64"},       # the bit matrix never fits: every prune takes the fallback
+    "multi_kernel_prune_no_spec": {"BSLV_K2_LDS": "64", "BSLV_NO_SPEC": "1"},
+}
+
+
+class hooks:
+    def __init__(self, env):
+        self.env = env
+
+    def __enter__(self):
+        self.old = {k: os.environ.pop(k, None) for k in HOOKS}
+        os.environ.update(self.env)
+
+    def __exit__(self, *a):
+        for k in HOOKS:
+            os.environ.pop(k, None)
+        for k, v in self.old.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+def gpu_run(env, q, vals, k0, batch_mode, batch):
+    """first k0 dual vertices one by one (poly__add_vrtx), poly__intl_apprx, the rest through add_cuts in batches"""
+    with hooks(env):
+        G = PolyEngine(q, 0, None)
+        G.set_batch_mode(batch_mode)
+        rcs = [G.add(vals[i], 0) for i in range(k0)]
+        assert G.init() == 0
+        for b0 in range(k0, len(vals), batch):
+            rcs += list(G.add_cuts(vals[b0:b0 + batch], None))
+        G.dual_adjacency()
+        d = G.dump()
+        d["paths"] = G.path_stats()
+        G.close()
+    return rcs, d
+
+
+def check_paths(name, p, hot_expected):
+    """the hook must have driven the run down the path it is meant to cover"""
+    assert p["single_cuts"] > 20, (name, p)
+    assert (p["hot_chunks"] > 0) == bool(hot_expected), (name, p)
+    if "no_spec" in name:
+        assert p["speculative"] == 0, (name, p)
+    elif name != "decline":            # (a declined cut is rerun and counted without speculation)
+        assert p["speculative"] > 20, (name, p)
+    if name == "decline":
+        assert p["declined"] > 10, (name, p)
+    if name.startswith("multi_kernel_prune"):
+        assert p["prune_fallbacks"] > 10, (name, p)
+    if name == "default":
+        assert p["declined"] == 0 and p["prune_fallbacks"] == 0, (name, p)
+
+
+def clustered_halfspaces(q, N, seed, spread=0.15):
+    """unit normals crowded around one direction: neighbouring cuts, every pair in conflict (what a batch of
+    newest-first Benson vertices looks like), so the multi-cut path falls back to sequences of single cuts"""
+    rng = np.random.default_rng(seed)
+    base = np.ones(q) / np.sqrt(q)
+    D = base + spread * rng.normal(size=(N, q))
+    return D / np.linalg.norm(D, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("q,N,seed", [(3, 300, 21), (4, 160, 22), (5, 120, 23)])
+def test_sequential_modes_match_oracle_slotwise(q, N, seed):
+    """batch mode 0: cuts in index order, so the oracle's slots and edge order must be reproduced exactly"""
+    D = np.vstack([ph.tangent_halfspaces(q, q + 3, seed), clustered_halfspaces(q, N, seed)])
+    O = ph.FlatPoly("oracle", q, 0, None)
+    rco = ph.run_sequence(O, D, None, q + 3)
+    O.dual_adjacency()
+    do = O.dump()
+    O.close()
+    for name, env in MODES.items():
+        rcg, dg = gpu_run(env, q, D, q + 3, 0, 64)
+        assert list(rco) == list(rcg), name
+        assert_slotwise_equal(do, dg)
+        check_paths(name, dg["paths"], hot_expected=False)
+
+
+@pytest.mark.parametrize("q,N,seed", [(4, 400, 31), (5, 300, 32)])
+def test_chunk_modes_agree_bitwise(q, N, seed):
+    """batch mode 1 on crowded cuts: the conflict pass gives up and runs sequences of single cuts, in hot mode by
+    default.  Every hook combination must give the dump of the default mode bit for bit, and the same polyhedron
+    as the oracle."""
+    D = np.vstack([ph.tangent_halfspaces(q, q + 3, seed), clustered_halfspaces(q, N, seed, 0.05)])
+    ref_rc, ref = gpu_run({}, q, D, q + 3, 1, 128)
+    for name, env in MODES.items():
+        if name == "default":
+            continue
+        rc, d = gpu_run(env, q, D, q + 3, 1, 128)
+        assert rc == ref_rc, name
+        for key in ("pu", "pi", "ps", "X", "du", "di", "Y", "E", "I", "DE"):
+            assert np.array_equal(d[key], ref[key]), (name, key)
+        check_paths(name, d["paths"], hot_expected="no_hot" not in name)
+    check_paths("default", ref["paths"], hot_expected=True)
+    O = ph.FlatPoly("oracle", q, 0, None)
+    ph.run_sequence(O, D, None, q + 3)
+    O.dual_adjacency()
+    do = O.dump()
+    O.close()
+    ph.assert_same(ph.canonical(do), ph.canonical(ref))
