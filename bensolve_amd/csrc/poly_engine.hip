@@ -47,6 +47,12 @@ struct PolyView {
     // the chunk began (ids >= nv_base); everything else is PLUS for every cut of the chunk.  hv == nullptr: all.
     const int *hv;
     int nhv, nv_base;
+    // hot mode, membership bitmaps of the elements with long incidence lists (extreme directions): lslot[v] = row of
+    // lbits (lstride words, one bit per facet rank) or -1.  An edge to such an element then costs one independent
+    // load per facet of its short end instead of a binary search (a chain of ~10 dependent loads) per facet.
+    int *lslot;
+    unsigned *lbits;
+    int lstride;
 };
 __device__ __host__ inline int vm_count(const PolyView &P, int nv) { return P.hv ? P.nhv + (nv - P.nv_base) : nv; }
 __device__ __forceinline__ int vm_id(const PolyView &P, int idx) { return P.hv ? (idx < P.nhv ? P.hv[idx] : P.nv_base + (idx - P.nhv)) : idx; }
@@ -353,6 +359,24 @@ __device__ __forceinline__ unsigned match_mask_long(const int (&A)[LCAP], int na
         m |= (unsigned)(p >= 0) << a;
     }
     return m;
+}
+// bit a: facet A[a] is in the membership bitmap row (see PolyView::lslot); 16 independent loads
+__device__ __forceinline__ unsigned match_mask_bits(const int (&A)[LCAP], int na, const unsigned *row)
+{
+    unsigned w[LCAP];
+#pragma unroll
+    for (int a = 0; a < LCAP; a++) w[a] = row[(a < na ? A[a] : 0) >> 5];
+    unsigned m = 0;
+#pragma unroll
+    for (int a = 0; a < LCAP; a++) m |= (unsigned)(a < na && ((w[a] >> (A[a] & 31)) & 1u)) << a;
+    return m;
+}
+// the bitmap row of element v, or nullptr
+__device__ __forceinline__ const unsigned *lrow(const PolyView &P, int v)
+{
+    if (!P.lslot) return nullptr;
+    const int sl = P.lslot[v];
+    return sl >= 0 ? P.lbits + (size_t)sl * P.lstride : nullptr;
 }
 __device__ __forceinline__ int isect_count_fast(const int *a, int na, const int *b, int nb)
 {
@@ -1047,10 +1071,25 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
                     if (cross) t.c = __popc(m) + 1;
                     else {
                         unsigned char *K = P.keep + P.inc_off[ia];
-                        while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; set_keep(K, a); }
+                        while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // short list: plain stores, nothing to wait for
                     }
-                } else if (cross) t.c = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
-                else mark_keep(P, ed, Z, counters);
+                } else {
+                    // one short list, one long list with a membership bitmap (hot mode): a bit test per short entry
+                    const bool ashort = na <= nb;
+                    const int is = ashort ? ia : ib, il = ashort ? ib : ia, ns = ashort ? na : nb;
+                    const unsigned *row = ns <= LCAP ? lrow(P, il) : nullptr;
+                    if (row && (cross || ashort)) {              // (a marking edge needs positions in the ZERO element's list: A short)
+                        int RS[LCAP];
+                        load_list(P.pool + P.inc_off[is], ns, RS);
+                        unsigned m = match_mask_bits(RS, ns, row);
+                        if (cross) t.c = __popc(m) + 1;
+                        else {
+                            unsigned char *K = P.keep + P.inc_off[ia];
+                            while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // short list: plain stores, nothing to wait for
+                        }
+                    } else if (cross) t.c = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
+                    else mark_keep(P, ed, Z, counters);
+                }
                 if (cross) ecount[e] = t.c;
                 if (dbg && tq3) {
                     const unsigned long long tq4 = wall_clock64();
@@ -1146,7 +1185,9 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
                 const bool ashort = na <= nb;
                 int S[LCAP], pos[LCAP];
                 load_list(ashort ? A : Bp, ashort ? na : nb, S);
-                const unsigned m = match_mask_long(S, ashort ? na : nb, ashort ? Bp : A, ashort ? nb : na, pos);
+                const unsigned *row = lrow(P, ashort ? pl : mi);
+                const unsigned m = row ? match_mask_bits(S, ashort ? na : nb, row)
+                                       : match_mask_long(S, ashort ? na : nb, ashort ? Bp : A, ashort ? nb : na, pos);
 #pragma unroll
                 for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = S[a];
             } else {
@@ -1190,16 +1231,27 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             const int nn = __shfl(n, src, WAVE), vv = __shfl(i, src, WAVE);
             const int zid = zmarks_find(Z, counters, vv);
             const int *row = zid >= 0 ? Z.rows + (size_t)zid * Z.stride : nullptr;
+            // its membership bitmap (hot mode) is rebuilt with the list: nobody reads it in this launch (crossing
+            // edges join MINUS and PLUS elements, this one is ZERO)
+            unsigned *lb = const_cast<unsigned *>(lrow(P, vv));
+            if (lb) {
+                for (int w = lane; w < P.lstride; w += WAVE) lb[w] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
             int base = 0;
             for (int j0 = 0; j0 < nn; j0 += WAVE) {
                 const int j = j0 + lane;
                 const int g = j < nn ? P.pool[oo + j] : 0;
                 const bool k = j < nn && (row ? row[g] == Z.stamp : P.keep[oo + j] != 0);
                 const unsigned long long bm = __ballot(k);
-                if (k) { P.pool[on + base + __popcll(bm & ((1ull << lane) - 1ull))] = g; if (!row) P.keep[oo + j] = 0; }
+                if (k) {
+                    P.pool[on + base + __popcll(bm & ((1ull << lane) - 1ull))] = g;
+                    if (!row) P.keep[oo + j] = 0;
+                    if (lb) atomicOr(&lb[g >> 5], 1u << (g & 31));
+                }
                 base += __popcll(bm);
             }
-            if (lane == 0) { P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; }
+            if (lane == 0) { P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; if (lb) atomicOr(&lb[facet >> 5], 1u << (facet & 31)); }
         }
     }
     if (!valid) return;
@@ -1482,6 +1534,27 @@ __global__ __launch_bounds__(PB) void k_hotv_emit(PolyView P, const int *tc, int
     Tri ex = block_exscan(t, &tot, lds);
     if (t.a) hv[bpre[blockIdx.x].a + ex.a] = i;
 }
+// membership bitmaps of the hot elements with long lists: one wave per hot element
+__global__ __launch_bounds__(PB) void k_lbits_build(PolyView P, int nhv, int maxslots, int *nslots)
+{
+    const int idx = blockIdx.x * (PB / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= nhv) return;
+    const int v = P.hv[idx], n = P.inc_len[v];
+    if (n <= LONGN) return;
+    int sl = 0;
+    if (lane == 0) sl = atomicAdd(nslots, 1);
+    sl = __shfl(sl, 0, WAVE);
+    if (sl >= maxslots) return;                 // (table full: this element keeps the binary search)
+    unsigned *row = P.lbits + (size_t)sl * P.lstride;
+    const int *L = P.pool + P.inc_off[v];
+    for (int j = lane; j < n; j += WAVE) { const int g = L[j]; atomicOr(&row[g >> 5], 1u << (g & 31)); }
+    if (lane == 0) P.lslot[v] = sl;
+}
+__global__ void k_lbits_reset(PolyView P, int nhv)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nhv) P.lslot[P.hv[idx]] = -1;
+}
 // edges with a touched end -> EH (order kept) with their position in E; alive[e] = 1 for the others
 __global__ __launch_bounds__(PB) void k_hote_flags(const int2 *E, int ne, const int *tc, Tri *bsum)
 {
@@ -1697,6 +1770,8 @@ struct bslv_poly {
     struct EdgeSet { int2 *E[2] = {nullptr, nullptr}; int *EP[2] = {nullptr, nullptr}; unsigned char *eflag = nullptr; int ecap = 0, ne = 0, ecur = 0; } full, hotbuf;
     unsigned char *alive = nullptr; int alivecap = 0;     // per edge of the full list: still there at the end of the chunk
     int *hv_d = nullptr; int hvcap = 0;                   // hot elements
+    int *lslot_d = nullptr; int lslotcap = 0;             // per element: row of its membership bitmap or -1 (all -1 outside hot mode)
+    unsigned *lbits_d = nullptr; size_t lbitscap = 0; int *lnslots_d = nullptr;
     long hot_chunks = 0, hot_elems = 0, hot_edges = 0;
     long n_spec = 0, n_declined = 0, n_k2_fallback = 0, n_single = 0;     // bslv_poly_path_stats
     double tm_hot_begin = 0, tm_seq = 0, tm_hot_end = 0, tm_add_cuts = 0; long tm_seq_cuts = 0;   // host wall clock (ms), printed at destroy with BSLV_TIMING
@@ -1803,6 +1878,13 @@ static int ensure_vcap(bslv_poly *h, int need)
     if ((rc = grow(&P.inc_off, h->nv, ncap, h->stream))) return rc;
     if ((rc = grow(&P.inc_len, h->nv, ncap, h->stream))) return rc;
     if ((rc = grow(&h->members, 0, ncap, h->stream))) return rc;
+    {   // membership-bitmap slots: -1 everywhere except on the long elements of a hot chunk
+        const int old = h->lslotcap;
+        if ((rc = grow(&h->lslot_d, (size_t)old, (size_t)ncap, h->stream))) return rc;
+        HIP_TRY(hipMemsetAsync(h->lslot_d + old, 0xFF, (size_t)(ncap - old) * sizeof(int), h->stream));
+        h->lslotcap = ncap;
+        if (P.lslot) P.lslot = h->lslot_d;
+    }
     P.cap = ncap;
     return 0;
 }
@@ -2202,6 +2284,18 @@ static int hot_begin(bslv_poly *h, const int *tc)
     F.E[0] = h->E[0]; F.E[1] = h->E[1]; F.eflag = h->eflag; F.ecap = h->ecap; F.ne = ne; F.ecur = h->ecur;
     h->E[0] = H.E[0]; h->E[1] = H.E[1]; h->EP[0] = H.EP[0]; h->EP[1] = H.EP[1]; h->eflag = H.eflag; h->ecap = H.ecap; h->ne = neh; h->ecur = 0;
     h->P.hv = h->hv_d; h->P.nhv = nhv; h->P.nv_base = nv;
+    {   // membership bitmaps of the hot elements with long lists; ranks up to those this chunk can add
+        constexpr int LMAX = 64;
+        const int stride = ((int)h->facet_of_rank.size() + 1024 + 63) / 32;
+        const size_t need = (size_t)LMAX * stride;
+        if (need > h->lbitscap) { const size_t nc = std::max(need, h->lbitscap * 2); if ((rc = grow(&h->lbits_d, 0, nc, s))) return rc; h->lbitscap = nc; }
+        if (!h->lnslots_d && (rc = grow(&h->lnslots_d, 0, 4, s))) return rc;
+        HIP_TRY(hipMemsetAsync(h->lbits_d, 0, need * sizeof(unsigned), s));
+        HIP_TRY(hipMemsetAsync(h->lnslots_d, 0, sizeof(int), s));
+        h->P.lslot = h->lslot_d; h->P.lbits = h->lbits_d; h->P.lstride = stride;
+        if (nhv > 0) hipLaunchKernelGGL(k_lbits_build, dim3((nhv + PB / WAVE - 1) / (PB / WAVE)), dim3(PB), 0, s, h->P, nhv, LMAX, h->lnslots_d);
+        HIP_TRY(hipGetLastError());
+    }
     h->hot = true;
     h->pre_f = -1;
     h->hot_chunks++; h->hot_elems += nhv; h->hot_edges += neh;
@@ -2221,6 +2315,8 @@ static int hot_end(bslv_poly *h)
     const int2 *EH = h->E[h->ecur];
     const int *EPc = h->EP[h->ecur];
     h->E[0] = F.E[0]; h->E[1] = F.E[1]; h->EP[0] = h->EP[1] = nullptr; h->eflag = F.eflag; h->ecap = F.ecap; h->ne = F.ne; h->ecur = F.ecur;
+    if (h->P.nhv > 0) hipLaunchKernelGGL(k_lbits_reset, dim3((h->P.nhv + 255) / 256), dim3(256), 0, s, h->P, h->P.nhv);
+    h->P.lslot = nullptr; h->P.lbits = nullptr; h->P.lstride = 0;
     h->P.hv = nullptr; h->P.nhv = 0; h->P.nv_base = 0;
     h->hot = false;
     h->pre_f = -1;
@@ -2375,7 +2471,7 @@ void bslv_poly_destroy(bslv_poly *h)
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
-    fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount);
+    fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
