@@ -86,6 +86,19 @@ __device__ Tri block_exscan(Tri v, Tri *tot, Tri *lds /* >= 16 */)
     ex.a -= v.a; ex.b -= v.b; ex.c -= v.c;
     return ex;
 }
+// sum of a Tri over the workgroup (result in every thread)
+__device__ __forceinline__ Tri block_sum(Tri v, Tri *lds /* >= 16 */)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v.a += __shfl_xor(v.a, o, WAVE); v.b += __shfl_xor(v.b, o, WAVE); v.c += __shfl_xor(v.c, o, WAVE); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    Tri r{0, 0, 0};
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) r = tri_add(r, lds[w]);
+    __syncthreads();
+    return r;
+}
 // scan of per-block sums by one workgroup; sums[] becomes exclusive prefixes, totals[0] the grand total
 // host mailbox in mapped pinned memory: the scan tail publishes totals (and the classify counters)
 // straight to the host, which spins on `seq` instead of paying a stream synchronise per readback
@@ -1114,13 +1127,31 @@ template <int D>
 __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, const int2 *E, int ne_ub, const int *ne_dev, int nbe,
                                               const unsigned char *eflag, const int *ecount, const Tri *ebpre, const Tri *vbpre, const Tri *totals,
                                               int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members, ZMarks Z, const int *counters, const CutDev *cd,
-                                              const int *EPold, int *EPnew)
+                                              const int *EPold, int *EPnew, int own_scan, ScanArgs A)
 {
-    if (cd) {                          // speculative launch: the device's own verdict on round A
+    __shared__ Tri lds[16];
+    Tri pre_e{0, 0, 0}, pre_v{0, 0, 0};
+    int nsurv_all = 0;
+    if (own_scan) {
+        // small grid (hot mode): no k_scan2 launch in between -- every workgroup sums the block sums of k_flags2 itself
+        // (its own prefix and the totals), reaches the verdict of round A from them, and workgroup 0 publishes it
+        const bool eblock = (int)blockIdx.x < nbe;
+        const int mye = eblock ? nbe - 1 - (int)blockIdx.x : 0, myv = eblock ? 0 : (int)gridDim.x - 1 - (int)blockIdx.x;
+        Tri pe{0, 0, 0}, te{0, 0, 0}, pv{0, 0, 0};
+        for (int i = threadIdx.x; i < A.nbe; i += PB) { const Tri v = A.ebsum[i]; te = tri_add(te, v); if (eblock && i < mye) pe = tri_add(pe, v); }
+        if (!eblock) for (int i = threadIdx.x; i < myv; i += PB) pv = tri_add(pv, A.vbsum[i]);
+        te = block_sum(te, lds);
+        if (eblock) pre_e = block_sum(pe, lds); else pre_v = block_sum(pv, lds);
+        if (blockIdx.x == 0 && threadIdx.x == 0) publish_round_a(A, te);
+        const bool go = A.counters[0] > 0 && !*A.abort_flag && te.b <= A.cross_ub && A.nv0 + te.b <= A.vcap &&
+                        (unsigned long long)A.poolused + (unsigned)te.c + (unsigned)A.counters[2] <= A.poolcap;
+        if (!go) return;
+        pool_z = A.poolused + (unsigned)te.c;
+        nsurv_all = te.a;
+    } else if (cd) {                   // speculative launch behind k_scan2: the device's own verdict on round A
         if (!cd->go) return;
         pool_z = cd->pool_z;
     }
-    __shared__ Tri lds[16];
     Tri t{0, 0, 0};
     Tri tot;
     if ((int)blockIdx.x < nbe) {              // back to front, as k_flags2
@@ -1136,7 +1167,8 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
         }
         Tri ex = block_exscan(t, &tot, lds);
         if (e >= ne) return;
-        ex = tri_add(ex, ebpre[eb]);
+        ex = tri_add(ex, own_scan ? pre_e : ebpre[eb]);
+        if (!own_scan) nsurv_all = totals[0].a;
         const int d = D > 0 ? D : P.d;
         if (f == 1 || f == 4) { Enew[ex.a] = ed; if (EPold) EPnew[ex.a] = EPold[e]; }      // (hot mode: where the edge sat before the chunk)
         else if (f == 2 || f == 3) {
@@ -1202,8 +1234,8 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             out[n++] = facet;
             P.inc_off[w] = off;
             P.inc_len[w] = n;
-            Enew[totals[0].a + ex.b] = int2{w, pl};
-            if (EPold) EPnew[totals[0].a + ex.b] = -1;
+            Enew[nsurv_all + ex.b] = int2{w, pl};
+            if (EPold) EPnew[nsurv_all + ex.b] = -1;
         }
         return;
     }
@@ -1219,7 +1251,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
         if (c == 0) { off_old = P.inc_off[i]; n = P.inc_len[i]; t.a = 1; t.c = n + 1; }
     }
     Tri ex = block_exscan(t, &tot, lds);
-    ex = tri_add(ex, vbpre[b]);
+    ex = tri_add(ex, own_scan ? pre_v : vbpre[b]);
     const unsigned off_new = pool_z + (unsigned)ex.c;
     const bool longz = (c == 0) && n > LONGN;
     {   // long lists (extreme directions): ordered compaction by the whole wave (ballot ranks), then the new facet
@@ -2132,12 +2164,13 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         // second launch: an agent-scope fence per workgroup writes the L2 back)
         hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, h->ecount, ebsum, vbsum, Z,
                            h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
-        hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, SA);
+        const bool own_scan = spec && nbe + nbv <= 1024;      // few workgroups: k_emit2 sums the block sums itself, no scan launch
+        if (!own_scan) hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, SA);
         if (spec) {
             // ---- round B, queued on the device's own verdict ----
             launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne_ub, ne_dev, nbe, (const unsigned char *)h->eflag, (const int *)h->ecount, (const Tri *)ebsum, (const Tri *)vbsum,
                          (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, h->poolused, 0u, h->members, Z, (const int *)counters, (const CutDev *)cd,
-                         (const int *)h->EP[h->ecur], h->EP[1 - h->ecur]);
+                         (const int *)h->EP[h->ecur], h->EP[1 - h->ecur], own_scan ? 1 : 0, SA);
             spec_ns = -1;
             int ncb = 0;                       // workgroups of the prune launch that classify the next halfspace
             if (next_f >= 0) {
@@ -2206,7 +2239,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
         launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne0, (const int *)nullptr, nbe, (const unsigned char *)h->eflag, (const int *)h->ecount, (const Tri *)ebsum, (const Tri *)vbsum,
                      (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, pool_e, pool_z, h->members, Z, counters, (const CutDev *)nullptr,
-                     (const int *)h->EP[h->ecur], h->EP[1 - h->ecur]);
+                     (const int *)h->EP[h->ecur], h->EP[1 - h->ecur], 0, ScanArgs{});
     }
     h->poolused += (unsigned)te.c + (unsigned)zero_ub;
     h->nv = nv0 + ncross;
