@@ -1318,6 +1318,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
 //   P6 ordered emission at E[ebase..)
 // Falls back (mail t.b = 1) when the bit matrix does not fit; the host then runs the multi-kernel path.
 constexpr int K2T = 1024, K2_MAXNM = 512, K2_MAXLONG = 64;
+constexpr int K2_HASH_LOG = 13, K2_HASH = 1 << K2_HASH_LOG;      // LDS hash table of the facets in the member lists (64 KB)
 __device__ __forceinline__ void pair_decode(long long p, int nm, int &i, int &j)
 {
     const double b2 = 2.0 * nm - 1.0;
@@ -1454,7 +1455,7 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     const long long npairs = (long long)nm * (nm - 1) / 2;
     const int nadjw = (int)((npairs + 31) / 32);
     unsigned *adj_bits = (unsigned *)k2_dyn;
-    unsigned long long *bits = k2_dyn + (nadjw + 1) / 2;
+    unsigned long long *bits = k2_dyn + (nadjw + 1) / 2;       // (behind the hash table when that is used, see P1)
     const long long bits_cap = (long long)lds_words - (nadjw + 1) / 2;
     if (bits_cap < 0) {                 // not even the pair bitmap fits (uniform): multi-kernel prune
         if (threadIdx.x == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; __threadfence_system(); mail->seq = seq; }
@@ -1474,33 +1475,77 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     __syncthreads();
     const int nlong = s_nlong < K2_MAXLONG ? s_nlong : K2_MAXLONG;
     K2_PHASE(0);
-    // P1: count the member lists a facet occurs in; the second one to arrive gives it its local id
-    k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) {
-        if (atomicAdd(&fcount[g], 1) == 1) __hip_atomic_store(&flocal[g], atomicAdd(&s_nloc, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    });
-    __threadfence_block();
+    // P1-P3: which facets occur in at least two member lists (only those can be mutual) -> local ids -> bit matrix.
+    // Few list entries in all (the usual case): an open-addressing hash table in LDS, keyed by facet rank -- LDS atomics
+    // instead of returning atomics on global memory (two memory latencies per phase).  Otherwise the counters in
+    // global memory (fcount / flocal, zero between cuts).
+    __shared__ int s_total;
+    if (tid == 0) s_total = 0;
     __syncthreads();
+    {
+        int part = 0;
+        for (int m = tid; m < nm; m += K2T) part += s_len[m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+        if ((tid & 63) == 0 && part) atomicAdd(&s_total, part);
+    }
+    __syncthreads();
+    const bool use_hash = 2 * s_total <= K2_HASH && (long long)K2_HASH <= bits_cap;        // load factor <= 1/2 (uniform)
+    int *hkey = (int *)bits, *hval = hkey + K2_HASH;                 // the table sits in front of the bit matrix
+    if (use_hash) bits += K2_HASH;                                   // (K2_HASH ints of keys + K2_HASH of values = K2_HASH 64-bit words)
+    const long long bcap = use_hash ? bits_cap - K2_HASH : bits_cap;
+    auto hslot = [&](int g) {                                        // slot of key g (inserted if absent)
+        unsigned sl = ((unsigned)g * 2654435761u) >> (32 - K2_HASH_LOG);
+        for (;;) {
+            const int k = atomicCAS(&hkey[sl], -1, g);
+            if (k == -1 || k == g) return (int)sl;
+            sl = (sl + 1) & (K2_HASH - 1);
+        }
+    };
+    if (use_hash) {
+        for (int w = tid; w < K2_HASH; w += K2T) { hkey[w] = -1; hval[w] = 0; }
+        __syncthreads();
+        k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { atomicAdd(&hval[hslot(g)], 1); });
+        __syncthreads();
+        for (int w = tid; w < K2_HASH; w += K2T) hval[w] = hval[w] >= 2 ? (0x40000000 | atomicAdd(&s_nloc, 1)) : 0;
+        __syncthreads();
+    } else {
+        k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) {
+            if (atomicAdd(&fcount[g], 1) == 1) __hip_atomic_store(&flocal[g], atomicAdd(&s_nloc, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        });
+        __threadfence_block();
+        __syncthreads();
+    }
     K2_PHASE(1);
     K2_PHASE(2);
     const int W = (s_nloc + 63) >> 6, NW = (nm + 63) >> 6;
     unsigned long long *rows = bits + W * nm;        // rows[f * NW + k]: members on local facet f
-    if ((long long)W * nm + (long long)W * 64 * NW > bits_cap) {             // uniform: every thread sees the same s_nloc
-        k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
+    if ((long long)W * nm + (long long)W * 64 * NW > bcap) {             // uniform: every thread sees the same s_nloc
+        if (!use_hash) k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
         if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; __threadfence_system(); mail->seq = seq; }
         return;
     }
     for (int w = tid; w < W * nm + W * 64 * NW; w += K2T) bits[w] = 0ull;
     __syncthreads();
     // P3
-    k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int m, int g) {
-        if (__hip_atomic_load(&fcount[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2) return;
-        const int id = __hip_atomic_load(&flocal[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicOr(&bits[(id >> 6) * nm + m], 1ull << (id & 63));
-        atomicOr(&rows[id * NW + (m >> 6)], 1ull << (m & 63));
-    });
+    if (use_hash)
+        k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int m, int g) {
+            const int v = hval[hslot(g)];
+            if (!(v & 0x40000000)) return;
+            const int id = v & 0x3FFFFFFF;
+            atomicOr(&bits[(id >> 6) * nm + m], 1ull << (id & 63));
+            atomicOr(&rows[id * NW + (m >> 6)], 1ull << (m & 63));
+        });
+    else
+        k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int m, int g) {
+            if (__hip_atomic_load(&fcount[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2) return;
+            const int id = __hip_atomic_load(&flocal[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(&bits[(id >> 6) * nm + m], 1ull << (id & 63));
+            atomicOr(&rows[id * NW + (m >> 6)], 1ull << (m & 63));
+        });
     __syncthreads();
-    // the counts go back to zero for the next cut (plain stores, nothing waits for them)
-    k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
+    // the global counts go back to zero for the next cut (plain stores, nothing waits for them)
+    if (!use_hash) k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
     K2_PHASE(3);
     // P4+P5 (k2_pairs)
     if (NW <= 1) k2_pairs<1>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
