@@ -1390,27 +1390,31 @@ __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const uns
     };
     // Only a fraction of the pairs are candidates; sweeping them where they are found would leave most lanes of
     // the wave idle, so each wave queues its candidates (LDS) and sweeps 64 at a time.
+    // Pairs are visited row by row (wave w takes rows w, w+16, ...; lanes run over j): column i is one broadcast
+    // read per row and no pair index has to be decoded -- the one workgroup is instruction-bound here.
     int qn = 0;                                    // wave-uniform
     int *q = queue[wave];
-    for (int p0 = 0; p0 < npairs; p0 += K2T) {
-        const int p = p0 + (int)threadIdx.x;
-        bool cand = false;
-        if (p < npairs) {
-            int i, j;
-            pair_decode32(p, nm, i, j);
-            int nmut = 0;
-            for (int w = 0; w < W; w++) nmut += __popcll(bits[w * nm + i] & bits[w * nm + j]);
-            if (d == 1) atomicOr(&adj_bits[p >> 5], 1u << (p & 31));
-            else cand = nmut >= d - 1;
-        }
-        const unsigned long long bm = __ballot(cand);
-        if (cand) q[qn + __popcll(bm & ((1ull << lane) - 1ull))] = p;
-        qn += __popcll(bm);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (qn >= WAVE) {
-            qn -= WAVE;
-            sweep(q[qn + lane]);
+    for (int i = wave; i < nm - 1; i += K2T / WAVE) {
+        const int rowbase = i * (2 * nm - i - 1) / 2 - (i + 1);          // pair index of (i, j) = rowbase + j
+        for (int j0 = i + 1; j0 < nm; j0 += WAVE) {
+            const int j = j0 + lane;
+            bool cand = false;
+            if (j < nm) {
+                int nmut = 0;
+                for (int w = 0; w < W; w++) nmut += __popcll(bits[w * nm + i] & bits[w * nm + j]);
+                if (d == 1) atomicOr(&adj_bits[(rowbase + j) >> 5], 1u << ((rowbase + j) & 31));
+                else cand = nmut >= d - 1;
+            }
+            const unsigned long long bm = __ballot(cand);
+            if (bm == 0ull) continue;
+            if (cand) q[qn + __popcll(bm & ((1ull << lane) - 1ull))] = rowbase + j;
+            qn += __popcll(bm);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (qn >= WAVE) {
+                qn -= WAVE;
+                sweep(q[qn + lane]);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
         }
     }
     if (lane < qn) sweep(q[lane]);
