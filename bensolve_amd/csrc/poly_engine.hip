@@ -1561,6 +1561,7 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     K2_PHASE(5);
     // P6: adjacent pairs in lexicographic order; the 32 pairs of a bitmap word are consecutive, so (i, j) is
     // decoded once per word and stepped
+    int last_tot = 0;
     for (int w0 = 0; w0 < nadjw; w0 += K2T) {
         const int ww = w0 + tid;
         unsigned word = ww < nadjw ? adj_bits[ww] : 0u;
@@ -1568,24 +1569,27 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
         Tri tot;
         Tri ex = block_exscan(t, &tot, lds);
         int at = ebase + s_carry + ex.a;
-        if (word) {
+        while (word) {                      // (a few set bits per word: decode each)
+            const int bbit = __ffs((int)word) - 1;
+            word &= word - 1;
             int i, j;
-            pair_decode((long long)ww * 32, nm, i, j);
-            for (int bbit = 0; bbit < 32; bbit++) {
-                if ((word >> bbit) & 1u) { E[at] = int2{s_mem[i], s_mem[j]}; if (EP) EP[at] = -1; at++; }
-                if (++j == nm) { i++; j = i + 1; }
-            }
+            pair_decode32(ww * 32 + bbit, nm, i, j);
+            E[at] = int2{s_mem[i], s_mem[j]};
+            if (EP) EP[at] = -1;
+            at++;
         }
-        __syncthreads();
-        if (tid == 0) s_carry += tot.a;
-        __syncthreads();
+        if (w0 + K2T < nadjw) {             // (not after the last chunk: a barrier would wait for the edge stores)
+            __syncthreads();
+            if (tid == 0) s_carry += tot.a;
+            __syncthreads();
+        } else last_tot = tot.a;
     }
     K2_PHASE(6);
     if (tid == 0) {
         if (dbg) { dbg[7] += 1; dbg[8] += (unsigned long long)W; dbg[9] += (unsigned long long)s_nloc; }
-        Tri r{s_carry, 0, 0};
+        Tri r{s_carry + last_tot, 0, 0};
         totals[0] = r;
-        if (ne_dev) *ne_dev = ebase + s_carry;
+        if (ne_dev) *ne_dev = ebase + r.a;
         mail->t = r;
         __threadfence_system();
         mail->seq = seq;
