@@ -1090,16 +1090,21 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
                     // one short list, one long list with a membership bitmap (hot mode): a bit test per short entry
                     const bool ashort = na <= nb;
                     const int is = ashort ? ia : ib, il = ashort ? ib : ia, ns = ashort ? na : nb;
-                    const unsigned *row = ns <= LCAP ? lrow(P, il) : nullptr;
+                    const unsigned *row = ns <= LONGN ? lrow(P, il) : nullptr;
                     if (row && (cross || ashort)) {              // (a marking edge needs positions in the ZERO element's list: A short)
-                        int RS[LCAP];
-                        load_list(P.pool + P.inc_off[is], ns, RS);
-                        unsigned m = match_mask_bits(RS, ns, row);
-                        if (cross) t.c = __popc(m) + 1;
-                        else {
-                            unsigned char *K = P.keep + P.inc_off[ia];
-                            while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // short list: plain stores, nothing to wait for
+                        int cnt = 0;
+                        for (int c0 = 0; c0 < ns; c0 += LCAP) {  // 16 entries at a time (a point on 17..64 facets takes a few rounds)
+                            const int nc = ns - c0 < LCAP ? ns - c0 : LCAP;
+                            int RS[LCAP];
+                            load_list(P.pool + P.inc_off[is] + c0, nc, RS);
+                            unsigned m = match_mask_bits(RS, nc, row);
+                            if (cross) cnt += __popc(m);
+                            else {
+                                unsigned char *K = P.keep + P.inc_off[ia] + c0;
+                                while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // plain stores, nothing to wait for
+                            }
                         }
+                        if (cross) t.c = cnt + 1;
                     } else if (cross) t.c = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
                     else mark_keep(P, ed, Z, counters);
                 }
@@ -1223,12 +1228,27 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
 #pragma unroll
                 for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = S[a];
             } else {
-                int i = 0, j = 0;
-                while (i < na && j < nb) {
-                    int x = A[i], y = Bp[j];
-                    if (x == y) out[n++] = x;
-                    i += (x <= y);
-                    j += (y <= x);
+                const bool ashort = na <= nb;
+                const int ns = ashort ? na : nb;
+                const unsigned *row = ns <= LONGN ? lrow(P, ashort ? pl : mi) : nullptr;
+                if (row) {                           // 17..64 facets against a membership bitmap: rounds of 16 bit tests
+                    const int *S = ashort ? A : Bp;
+                    for (int c0 = 0; c0 < ns; c0 += LCAP) {
+                        const int nc = ns - c0 < LCAP ? ns - c0 : LCAP;
+                        int RS[LCAP];
+                        load_list(S + c0, nc, RS);
+                        const unsigned m = match_mask_bits(RS, nc, row);
+#pragma unroll
+                        for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = RS[a];
+                    }
+                } else {
+                    int i = 0, j = 0;
+                    while (i < na && j < nb) {
+                        int x = A[i], y = Bp[j];
+                        if (x == y) out[n++] = x;
+                        i += (x <= y);
+                        j += (y <= x);
+                    }
                 }
             }
             out[n++] = facet;
