@@ -1058,6 +1058,11 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
     if ((int)blockIdx.x < nbe) {
         const int eb = nbe - 1 - (int)blockIdx.x;
         const int ne = ne_dev ? *ne_dev : ne_ub;
+        // the long on-plane elements of this cut (ZMarks), fetched up front: uniform addresses, off the per-edge chains
+        const int nzl = counters[3] < ZMAX ? counters[3] : ZMAX;
+        int zl[ZMAX];
+#pragma unroll
+        for (int k = 0; k < ZMAX; k++) zl[k] = Z.zlist[k];
         const int e = eb * PB + threadIdx.x;
         if (e < ne) {
             const int2 ed = E[e];
@@ -1076,7 +1081,19 @@ __global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne
                 const int ia = (mark && ca != 0) ? ed.y : ed.x, ib = ia == ed.x ? ed.y : ed.x;      // A = the ZERO element of a marking edge
                 const int na = P.inc_len[ia], nb = P.inc_len[ib];
                 if (dbg && na + nb > 0) tq2 = wall_clock64();
-                if (na <= LCAP && nb <= LCAP) {
+                int zid = -1;
+                if (mark && na > LONGN) {
+#pragma unroll
+                    for (int k = 0; k < ZMAX; k++) if (k < nzl && zl[k] == ia) zid = k;
+                }
+                if (zid >= 0 && nb <= LCAP) {
+                    // ZERO element with a long list, PLUS end short: stamp the facets of the PLUS end in its ZMarks row
+                    int RB[LCAP];
+                    load_list(P.pool + P.inc_off[ib], nb, RB);
+                    int *zrow = Z.rows + (size_t)zid * Z.stride;
+#pragma unroll
+                    for (int b2 = 0; b2 < LCAP; b2++) if (b2 < nb) zrow[RB[b2]] = Z.stamp;
+                } else if (na <= LCAP && nb <= LCAP) {
                     int RA[LCAP], RB[LCAP];
                     load_list(P.pool + P.inc_off[ia], na, RA); load_list(P.pool + P.inc_off[ib], nb, RB);
                     unsigned m = match_mask(RA, na, RB);
@@ -2537,7 +2554,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
     if (const char *e = getenv("BSLV_CROSS_UB")) h->cross_ub = std::max(0, atoi(e));
     if (const char *e = getenv("BSLV_K2_LDS")) h->k2_lds = (size_t)std::max(64, atoi(e));      // test hook: a small value forces the multi-kernel prune
-    if (h->cutlog && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) { std::vector<unsigned long long> z(8192 * 16, 0ull); for (int k = 0; k < 8192; k++) z[16 * k + 12] = ~0ull; (void)hipMemcpy(h->fdbg, z.data(), z.size() * 8, hipMemcpyHostToDevice); }
+    if (h->cutlog && getenv("BSLV_FLAGS_DEBUG") && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) { std::vector<unsigned long long> z(8192 * 16, 0ull); for (int k = 0; k < 8192; k++) z[16 * k + 12] = ~0ull; (void)hipMemcpy(h->fdbg, z.data(), z.size() * 8, hipMemcpyHostToDevice); }
     if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
     // dual slot 0: "facet at infinity", ideal point (0,..,0,-1)  (bslv_poly.c:83-92)
