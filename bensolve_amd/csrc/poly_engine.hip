@@ -102,7 +102,7 @@ __device__ __forceinline__ Tri block_sum(Tri v, Tri *lds /* >= 16 */)
 // scan of per-block sums by one workgroup; sums[] becomes exclusive prefixes, totals[0] the grand total
 // host mailbox in mapped pinned memory: the scan tail publishes totals (and the classify counters)
 // straight to the host, which spins on `seq` instead of paying a stream synchronise per readback
-struct Mail { volatile int seq; int cnt[4]; Tri t; };
+struct Mail { volatile int seq; int cnt[4]; Tri t; Tri k2t; int k2seq; };    // k2t/k2seq: result of the prune that was in flight, forwarded by round A
 __global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *totals, Mail *mail = nullptr, const int *counters = nullptr, int seq = 0)
 {
     __shared__ Tri lds[16];
@@ -979,6 +979,7 @@ struct CutDev { int go, nminus, nzero, zero_ub, nsurv, ncross, newlen, ne0, nv_n
 struct ScanArgs {
     Tri *ebsum; int nbe; Tri *vbsum; int nbv; Tri *totals; Mail *mail; const int *counters; int ne_ub; const int *ne_dev; int seq;
     CutDev *cd; const int *abort_flag; int nv0, vcap; unsigned poolused, poolcap; int cross_ub;
+    const Mail *k2src;     // device-side result of the adjacency prune still unread by the host (or nullptr)
 };
 // scan of one array of block sums by the calling workgroup (any size): sums[] becomes exclusive prefixes
 __device__ __forceinline__ Tri scan_sums(Tri *sums, int nb, Tri *lds)
@@ -1013,6 +1014,7 @@ __device__ __forceinline__ void publish_round_a(const ScanArgs &A, Tri te)
         *A.cd = c;
     }
     A.mail->t = te;
+    if (A.k2src) { A.mail->k2t = A.k2src->t; A.mail->k2seq = A.k2src->seq; }
     for (int k = 0; k < 3; k++) A.mail->cnt[k] = A.counters[k];
     A.mail->cnt[3] = ne0;
     __threadfence_system();
@@ -1478,7 +1480,6 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
                 totals[0] = r;
                 if (ne_dev) *ne_dev = ebase;
                 mail->t = r;
-                __threadfence_system();
                 mail->seq = seq;
             }
             return;
@@ -1499,7 +1500,7 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     unsigned long long *bits = k2_dyn + (nadjw + 1) / 2;       // (behind the hash table when that is used, see P1)
     const long long bits_cap = (long long)lds_words - (nadjw + 1) / 2;
     if (bits_cap < 0) {                 // not even the pair bitmap fits (uniform): multi-kernel prune
-        if (threadIdx.x == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; __threadfence_system(); mail->seq = seq; }
+        if (threadIdx.x == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; mail->seq = seq; }
         return;
     }
     // P0: members (ZERO elements from k_emit2, then the new vertices), their lists
@@ -1563,7 +1564,7 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     unsigned long long *rows = bits + W * nm;        // rows[f * NW + k]: members on local facet f
     if ((long long)W * nm + (long long)W * 64 * NW > bcap) {             // uniform: every thread sees the same s_nloc
         if (!use_hash) k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
-        if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; __threadfence_system(); mail->seq = seq; }
+        if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; mail->seq = seq; }
         return;
     }
     for (int w = tid; w < W * nm + W * 64 * NW; w += K2T) bits[w] = 0ull;
@@ -1628,11 +1629,20 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
         totals[0] = r;
         if (ne_dev) *ne_dev = ebase + r.a;
         mail->t = r;
-        __threadfence_system();
         mail->seq = seq;
     }
 }
 
+
+// the result of a prune (device memory: a write to host memory at the very end of the kernel kept the NEXT launch
+// waiting for the PCIe acknowledgement, 5-6 us per cut) normally reaches the host with the mailbox of the next round A;
+// at the end of a sequence of cuts this kernel forwards it
+__global__ void k_forward_mail(const Mail *src, Mail *dst)
+{
+    dst->t = src->t;
+    __threadfence_system();
+    dst->seq = src->seq;
+}
 
 // ---------------- hot mode: set-up and merge (once per chunk of cuts) ----------------
 // elements some cut of the chunk touches (tc > 0, from k_classify_batch) -> hv (ascending); the others are PLUS for all
@@ -1896,13 +1906,15 @@ struct bslv_poly {
     unsigned *lbits_d = nullptr; size_t lbitscap = 0; int *lnslots_d = nullptr;
     long hot_chunks = 0, hot_elems = 0, hot_edges = 0;
     long n_spec = 0, n_declined = 0, n_k2_fallback = 0, n_single = 0;     // bslv_poly_path_stats
-    double tm_hot_begin = 0, tm_seq = 0, tm_hot_end = 0, tm_add_cuts = 0; long tm_seq_cuts = 0;   // host wall clock (ms), printed at destroy with BSLV_TIMING
+    double tm_hot_begin = 0, tm_seq = 0, tm_hot_end = 0, tm_add_cuts = 0; long tm_seq_cuts = 0;
+    double tm_launch[4] = {0, 0, 0, 0};      // us: queueing round A, k_emit2, all of round B, waiting for the mailbox   // host wall clock (ms), printed at destroy with BSLV_TIMING
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
     Tri *totals = nullptr;            // device, 4 entries
     int *counters = nullptr;          // device, 4 ints
     Tri *totals_h = nullptr; int *counters_h = nullptr;   // pinned
-    Mail *mail_h = nullptr, *mail_d = nullptr;          // mapped pinned mailbox (3 entries)
+    Mail *mail_h = nullptr, *mail_d = nullptr;          // mapped pinned mailbox (4 entries: round A, -, prune x2)
+    Mail *k2mail_d = nullptr;                           // device memory: where k2_fused leaves its result (2 slots)
     int *fstamp = nullptr, *flocal = nullptr, *nlocal = nullptr; int fcap = 0;   // local facet ids of the cut in flight
     unsigned long long *bits = nullptr; size_t bitscap = 0;                     // local incidence bit matrix
     int mailseq = 0;
@@ -2154,9 +2166,15 @@ static int settle_k2(bslv_poly *h, bool *redo = nullptr)
     if (redo) *redo = false;
     if (!h->pend_k2) return 0;
     int rc;
-    if ((rc = wait_mail(h, h->pend_slot, h->pend_seq))) return rc;
+    Tri tp;
+    if (h->mail_h[0].k2seq == h->pend_seq) tp = h->mail_h[0].k2t;          // came with the mailbox of the round A behind it
+    else {
+        hipLaunchKernelGGL(k_forward_mail, dim3(1), dim3(1), 0, h->stream, (const Mail *)(h->k2mail_d + (h->pend_slot - 2)), h->mail_d + h->pend_slot);
+        HIP_TRY(hipGetLastError());
+        if ((rc = wait_mail(h, h->pend_slot, h->pend_seq))) return rc;
+        tp = h->mail_h[h->pend_slot].t;
+    }
     h->pend_k2 = false;
-    const Tri tp = h->mail_h[h->pend_slot].t;
     h->ne = h->pend_ebase;
     if (tp.b == 1) {
         h->n_k2_fallback++;
@@ -2247,20 +2265,26 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         // ---- round A ----
         const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
         CutDev *cd = h->cutdev + cslot;
+        auto tl0 = std::chrono::steady_clock::now();
         if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters, h->zlist + ZMAX * cslot, (const int *)nullptr);
         const int seqA = ++h->mailseq;
-        const ScanArgs SA{ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA, cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap, h->cross_ub};
+        const ScanArgs SA{ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA, cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap, h->cross_ub,
+                          h->pend_k2 ? (const Mail *)(h->k2mail_d + (h->pend_slot - 2)) : (const Mail *)nullptr};
         // (letting the last workgroup of k_flags2 do the scans -- ticket + fences -- was measured SLOWER than this
         // second launch: an agent-scope fence per workgroup writes the L2 back)
         hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, h->ecount, ebsum, vbsum, Z,
                            h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
         const bool own_scan = spec && nbe + nbv <= 1024;      // few workgroups: k_emit2 sums the block sums itself, no scan launch
         if (!own_scan) hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, SA);
+        auto tl1 = std::chrono::steady_clock::now();
+        h->tm_launch[0] += std::chrono::duration<double, std::micro>(tl1 - tl0).count();
         if (spec) {
             // ---- round B, queued on the device's own verdict ----
             launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne_ub, ne_dev, nbe, (const unsigned char *)h->eflag, (const int *)h->ecount, (const Tri *)ebsum, (const Tri *)vbsum,
                          (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, h->poolused, 0u, h->members, Z, (const int *)counters, (const CutDev *)cd,
                          (const int *)h->EP[h->ecur], h->EP[1 - h->ecur], own_scan ? 1 : 0, SA);
+            auto tl2 = std::chrono::steady_clock::now();
+            h->tm_launch[1] += std::chrono::duration<double, std::micro>(tl2 - tl1).count();
             spec_ns = -1;
             int ncb = 0;                       // workgroups of the prune launch that classify the next halfspace
             if (next_f >= 0) {
@@ -2271,11 +2295,15 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             seqB = ++h->mailseq;
             slotB = 2 + (h->k2flip ^= 1);
             hipLaunchKernelGGL(k2_fused, dim3(1 + ncb), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
-                               h->ne_dev, h->totals + 2, h->mail_d + slotB, seqB, h->k2dbg, (const CutDev *)cd, h->abort_d, h->EP[1 - h->ecur],
+                               h->ne_dev, h->totals + 2, h->k2mail_d + (slotB - 2), seqB, h->k2dbg, (const CutDev *)cd, h->abort_d, h->EP[1 - h->ecur],
                                hn, h->counters + CSTRIDE * std::max(spec_ns, 0), h->zlist + ZMAX * std::max(spec_ns, 0));
         }
+        auto tl3 = std::chrono::steady_clock::now();
         HIP_TRY(hipGetLastError());
         if ((rc = wait_mail(h, 0, seqA))) return rc;
+        auto tl4 = std::chrono::steady_clock::now();
+        h->tm_launch[2] += std::chrono::duration<double, std::micro>(tl3 - tl1).count();
+        h->tm_launch[3] += std::chrono::duration<double, std::micro>(tl4 - tl3).count();
         bool redo;
         if ((rc = settle_k2(h, &redo))) return rc;
         if (!redo && spec && h->mail_h[0].cnt[0] > 0) {
@@ -2352,7 +2380,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             if (nm <= K2_MAXNM) {
                 const int sq = ++h->mailseq, sl = 2 + (h->k2flip ^= 1);
                 hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, h->fcount, h->flocal,
-                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->mail_d + sl, sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d, h->EP[h->ecur], hn, (int *)nullptr, (int *)nullptr);
+                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->k2mail_d + (sl - 2), sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d, h->EP[h->ecur], hn, (int *)nullptr, (int *)nullptr);
                 HIP_TRY(hipGetLastError());
                 h->pend_k2 = true; h->pend_seq = sq; h->pend_slot = sl; h->pend_ebase = h->ne;
                 h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_nzero = nzero; h->pend_nv0 = nv0; h->pend_ncross = ncross;
@@ -2534,7 +2562,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     h->P.d = dim;
     auto fail = [&](int code) { bslv_poly_destroy(h); return code; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
-    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * CSTRIDE * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->cutdev, CRING * sizeof(CutDev)) != hipSuccess ||
+    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * CSTRIDE * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->k2mail_d, 4 * sizeof(Mail)) != hipSuccess || hipMemset(h->k2mail_d, 0, 4 * sizeof(Mail)) != hipSuccess || hipMalloc(&h->cutdev, CRING * sizeof(CutDev)) != hipSuccess ||
         hipMalloc(&h->abort_d, 4 * sizeof(int)) != hipSuccess || hipMemset(h->abort_d, 0, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->zlist, CRING * ZMAX * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->mail_h, 4 * sizeof(Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -2571,7 +2599,9 @@ void bslv_poly_destroy(bslv_poly *h)
     if (getenv("BSLV_TIMING"))
         fprintf(stderr, "poly timing: add_cuts %.1f ms | hot_begin %.1f, sequences %.1f (%ld cuts, %.1f us each), hot_end %.1f ms | %ld hot chunks, %.0f elements, %.0f edges on average\n", h->tm_add_cuts,
                 h->tm_hot_begin, h->tm_seq, h->tm_seq_cuts, h->tm_seq_cuts ? h->tm_seq * 1e3 / h->tm_seq_cuts : 0.0, h->tm_hot_end, h->hot_chunks,
-                h->hot_chunks ? (double)h->hot_elems / h->hot_chunks : 0.0, h->hot_chunks ? (double)h->hot_edges / h->hot_chunks : 0.0);
+                h->hot_chunks ? (double)h->hot_elems / h->hot_chunks : 0.0, h->hot_chunks ? (double)h->hot_edges / h->hot_chunks : 0.0),
+        fprintf(stderr, "poly host per cut (us): queue round A %.1f, k_emit2 %.1f, round B in all %.1f, mailbox wait %.1f\n", h->tm_launch[0] / std::max(1L, h->n_single), h->tm_launch[1] / std::max(1L, h->n_single),
+                h->tm_launch[2] / std::max(1L, h->n_single), h->tm_launch[3] / std::max(1L, h->n_single));
     if (h->cutlog && h->fdbg) {
         std::vector<unsigned long long> t(8192 * 16);
         if (hipMemcpy(t.data(), h->fdbg, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -2592,7 +2622,7 @@ void bslv_poly_destroy(bslv_poly *h)
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
-    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
