@@ -33,6 +33,7 @@ void set_error(const char *fmt, ...)
 constexpr int NS_L = 0, NS_U = 1, NS_F = 2, NS_S = 3;
 constexpr int ST_RUNNING = -1;
 constexpr int MODE_NONE = 0, MODE_PIVOT = 1, MODE_REFRESH = 2;
+constexpr int REFRESH_AFTER = 32;      // pivots of one solve after which optimality is only declared on a recomputed beta
 constexpr double TOL_BND = 1e-9, TOL_DJ = 1e-9, TOL_PIV = 1e-9;
 constexpr double BIG = 1e7;   // artificial bound for dual-infeasible free columns
 constexpr int TR = 32;        // tableau rows per workgroup in k_update / k_init
@@ -51,9 +52,10 @@ struct LpView {
 struct BatchView {
     const int *src, *dst;
     const double *vlo, *vup;
-    int *status, *iters, *mode, *verified;
+    int *status, *iters, *mode, *verified;    // verified: bit 0 = beta is fresh, bit 1 = the solve started with a variable on an artificial bound
     PivDesc *desc;
     double *prow;
+    int *work, *nwork;      // LPs whose tableau changes in this lock-step iteration (k_select -> k_update), count per iteration
 };
 
 __device__ __forceinline__ double LO(const LpView &L, const BatchView &Bv, int b, int k)
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
         for (int i = threadIdx.x; i < L.M; i += NT) bh_d[i] = bh_s[i];
         for (int i = threadIdx.x; i < L.M + L.N; i += NT) pos_d[i] = pos_s[i];
     }
-    int dual_infeasible = 0;
+    int dual_infeasible = 0, bigm = 0;     // bigm: a nonbasic variable sits on an artificial (+-1e7) bound
     for (int j = threadIdx.x; j < L.ld; j += NT) {
         if (j >= L.N) { xN_d[j] = 0.0; continue; }
         int k = nh_s[j];
@@ -108,16 +110,18 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
             double dj = drow_s[j];
             if ((st == NS_F && fabs(dj) > 1e-7) || (st == NS_L && dj < -1e-7) || (st == NS_U && dj > 1e-7)) dual_infeasible = 1;
         }
+        { const unsigned char a = L.art[k]; if ((st == NS_L && (a & 1)) || (st == NS_U && (a & 2))) bigm = 1; }
         nh_d[j] = k;
         ns_d[j] = st;
         xN_d[j] = (st == NS_F) ? 0.0 : (st == NS_U ? up : lo);
     }
     dual_infeasible = __syncthreads_or(dual_infeasible);
+    bigm = __syncthreads_or(bigm);
     if (threadIdx.x == 0) {
         Bv.status[b] = dual_infeasible ? BSLV_LP_UNDEFINED : ST_RUNNING;
         Bv.iters[b] = 0;
         Bv.mode[b] = MODE_NONE;
-        Bv.verified[b] = 1;   // k_init recomputes beta from scratch
+        Bv.verified[b] = 1 | (bigm ? 2 : 0);   // k_init recomputes beta from scratch
     }
 }
 
@@ -194,7 +198,7 @@ __device__ __forceinline__ double block_min(double v, double *sv)
 // ---- k_select: dual simplex choice of (leaving row r, entering column q) for each running LP.
 //      Same rules as oracle/lp_dense.c dual_simplex(): largest bound violation, Harris two-pass
 //      ratio test with the largest |pivot| among the ties. ----
-__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact)
+__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact, int it)
 {
     __shared__ double sv[NT / WAVE];
     __shared__ int si[NT / WAVE];
@@ -224,8 +228,12 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     best = block_argmax(best, sv, si);
     const double *drow = T + (size_t)M * ld;
     if (best.i < 0) {
-        if (!Bv.verified[b]) {            // recompute beta from scratch before concluding
-            if (tid == 0) Bv.mode[b] = MODE_REFRESH;
+        // recompute beta from scratch before concluding -- unless this solve made only a few pivots since k_init computed
+        // it from scratch: the rank-1 updates of beta then carry ~1e-15 of error against tolerances of 1e-9, and the
+        // refresh is a full read of the tableau (4 MB per LP on S-mid, an eighth of the traffic of a 4-pivot solve)
+        // (Not when the solve started on an artificial bound: values of 1e7 leave rounding debris of 1e-9 in beta.)
+        if (!(Bv.verified[b] & 1) && (Bv.iters[b] > REFRESH_AFTER || (Bv.verified[b] & 2))) {
+            if (tid == 0) { Bv.mode[b] = MODE_REFRESH; Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b; }
             return;
         }
         // optimal for the bounded problem; unbounded if an artificial bound is active
@@ -265,8 +273,8 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     }
     th = block_min(th, sv);
     if (isinf(th)) {                      // no entering candidate: primal infeasible ...
-        if (!Bv.verified[b]) {            // ... unless the violation is rounding debris in beta: recompute it first
-            if (tid == 0) Bv.mode[b] = MODE_REFRESH;
+        if (!(Bv.verified[b] & 1)) {      // ... unless the violation is rounding debris in beta: recompute it first
+            if (tid == 0) { Bv.mode[b] = MODE_REFRESH; Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b; }
             return;
         }
         if (tid == 0) { Bv.status[b] = BSLV_LP_INFEASIBLE; Bv.mode[b] = MODE_NONE; }
@@ -304,7 +312,8 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         else if (below) { nstat[q] = NS_L; xN[q] = lo; }
         else { nstat[q] = NS_U; xN[q] = up; }
         Bv.mode[b] = MODE_PIVOT;
-        Bv.verified[b] = 0;
+        Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b;
+        Bv.verified[b] &= 2;
         Bv.iters[b] += 1;
     }
 }
@@ -314,23 +323,25 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
 //      row r: T[r][j] = -prow[j] * p (j != q), T[r][q] = p, beta[r] = enter_val.
 //      Row M (reduced costs, objective value) is updated by the same formula.
 //      Algorithmic traffic: one read + one write of the tableau = 16 B per element per pivot. ----
-__global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, const int *active, int nact, int tr /* rows per workgroup: 8, 16 or 32 */)
+__global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8, 16 or 32 */)
 {
     extern __shared__ double s_prow[];
-    if ((int)blockIdx.y >= nact) return;
-    const int b = active[blockIdx.y];
-    if (Bv.status[b] != ST_RUNNING) return;
+    // persistent grid over the work items (LP of this iteration's work list x row tile): LPs that finished or did not
+    // pivot cost nothing -- with one workgroup per (LP, tile) of the whole batch, the later lock-step iterations spent
+    // most of their time dispatching workgroups that returned at once
+    const int nitems = Bv.nwork[it] * tiles;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ld = L.ld, ld2 = ld >> 1;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = Bv.work[item / tiles], tile = item % tiles;
     const int mode = Bv.mode[b];
-    if (mode == MODE_NONE) return;
     int slot = Bv.dst[b];
     double *T = L.T + (size_t)slot * L.slotT;
     double *beta = L.beta + (size_t)slot * L.Mp1p;
-    const int ld = L.ld, ld2 = ld >> 1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (mode == MODE_REFRESH) {
         const double2 *x2 = reinterpret_cast<const double2 *>(L.xN + (size_t)slot * ld);
         for (int rr = wave; rr < tr; rr += NT / WAVE) {
-            int i = blockIdx.x * tr + rr;
+            int i = tile * tr + rr;
             if (i >= L.Mp1) break;
             const double2 *t2 = reinterpret_cast<const double2 *>(T + (size_t)i * ld);
             double acc = 0.0;
@@ -342,8 +353,8 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, const int
             acc = wave_sum(acc);
             if (lane == 0) beta[i] = acc;
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) Bv.verified[b] = 1;
-        return;
+        if (tile == 0 && threadIdx.x == 0) Bv.verified[b] |= 1;
+        continue;
     }
     const PivDesc d = Bv.desc[b];
     {
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, const int
     // are fetched first, then both rows' loads are in flight before the first store (more bytes in
     // flight per CU than one row at a time)
     const int RPW = tr / (NT / WAVE);
-    const int row0 = blockIdx.x * tr + wave * RPW;
+    const int row0 = tile * tr + wave * RPW;
     for (int rr = 0; rr < RPW; rr += 2) {
         const int i0 = row0 + rr, i1 = i0 + 1;
         if (i0 >= L.Mp1) break;
@@ -390,6 +401,8 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, const int
             if (do0) beta[i0] = piv0 ? d.enter_val : fma(-f0, d.pbeta, beta[i0]);
             if (do1) beta[i1] = piv1 ? d.enter_val : fma(-f1, d.pbeta, beta[i1]);
         }
+    }
+    __syncthreads();          // the pivot row in LDS is reused by the next work item
     }
 }
 
@@ -441,6 +454,8 @@ struct bslv_lpq {
     // batch buffers
     int Bcap = 0;
     int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
+    int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
+    int upd_grid = 32768;             // workgroups of the persistent k_update (BSLV_UPD_GRID; 1024..32768 measured equal within 2 %)    // work list of a lock-step iteration, its length per iteration
     int *active_d = nullptr, *active_h = nullptr;       // compacted indices of the LPs still running (device / pinned)
     double *vlo_d = nullptr, *vup_d = nullptr, *prow_d = nullptr, *out_d = nullptr;
     size_t out_cap = 0;
@@ -459,7 +474,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     if (B <= h->Bcap) return 0;
     int cap = std::max(B, h->Bcap * 2);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
-    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d);
+    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d); fr(h->work_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
@@ -469,6 +484,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     HIP_TRY(hipMalloc(&h->status_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->iters_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->mode_d, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->work_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->ver_d, cap * sizeof(int)));
     size_t vc = (size_t)std::max(1, h->L.vcnt);
     HIP_TRY(hipMalloc(&h->vlo_d, cap * vc * sizeof(double)));
@@ -488,6 +504,7 @@ static BatchView bview(bslv_lpq *h)
     v.src = h->src_d; v.dst = h->dst_d; v.vlo = h->vlo_d; v.vup = h->vup_d;
     v.status = h->status_d; v.iters = h->iters_d; v.mode = h->mode_d; v.verified = h->ver_d;
     v.desc = h->desc_d; v.prow = h->prow_d;
+    v.work = h->work_d; v.nwork = h->nwork_d;
     return v;
 }
 
@@ -595,7 +612,7 @@ void bslv_lpq_destroy(bslv_lpq *h)
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
-    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
     for (auto &e : h->evpool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -661,6 +678,12 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
         HIP_TRY(hipMemcpyAsync(h->vlo_d, vlo, (size_t)B * L.vcnt * sizeof(double), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(h->vup_d, vup, (size_t)B * L.vcnt * sizeof(double), hipMemcpyHostToDevice, s));
     }
+    if (const char *e = getenv("BSLV_UPD_GRID")) h->upd_grid = std::max(64, atoi(e));
+    {   // one work-list length per lock-step iteration, zeroed here: no reset between iterations
+        const int need = L.maxit + 64;
+        if (need > h->nworkcap) { if (h->nwork_d) (void)hipFree(h->nwork_d); h->nwork_d = nullptr; HIP_TRY(hipMalloc(&h->nwork_d, need * sizeof(int))); h->nworkcap = need; }
+        HIP_TRY(hipMemsetAsync(h->nwork_d, 0, need * sizeof(int), s));
+    }
     BatchView bv = bview(h);
     const int tiles = (L.Mp1 + TR - 1) / TR;
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(NT), 0, s, L, bv, B);
@@ -674,7 +697,7 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     h->last_update_ms = 0;
     while (running > 0 && it < L.maxit + 8) {
         for (int c = 0; c < chunk; c++, it++) {
-            hipLaunchKernelGGL(k_select, dim3(running), dim3(NT), 0, s, L, bv, h->active_d, running);
+            hipLaunchKernelGGL(k_select, dim3(running), dim3(NT), 0, s, L, bv, h->active_d, running, it);
             if (h->profile) {
                 if (nev == h->evpool.size()) {
                     hipEvent_t a, b2;
@@ -685,7 +708,8 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
             }
             // few LPs left: smaller row tiles keep >= ~2k workgroups in flight
             const int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : 8);
-            hipLaunchKernelGGL(k_update, dim3((L.Mp1 + tr - 1) / tr, running), dim3(NT), lds, s, L, bv, h->active_d, running, tr);
+            const int ntile = (L.Mp1 + tr - 1) / tr;
+            hipLaunchKernelGGL(k_update, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), lds, s, L, bv, it, ntile, tr);
             if (h->profile) { HIP_TRY(hipEventRecord(h->evpool[nev].second, s)); nev++; }
         }
         HIP_TRY(hipGetLastError());
