@@ -125,7 +125,10 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
     }
 }
 
-// ---- k_init: T_dst = T_src (streamed once) and beta_dst = T . xN_dst, one wave per row ----
+// ---- k_init: beta_dst = T_src . xN_dst, one wave per row, and the reduced-cost row T_dst[M] = T_src[M].  The rest of the
+//      parent's tableau is NOT copied here: the first pivot of the solve reads the parent and writes the new slot
+//      (k_update), which saves one write and one read of the tableau per LP; solves without a pivot are copied by
+//      k_copy_unpivoted at the end. ----
 __global__ __launch_bounds__(NT) void k_init(LpView L, BatchView Bv, int B)
 {
     int b = blockIdx.y;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(NT) void k_init(LpView L, BatchView Bv, int B)
         for (int j2 = lane; j2 < ld2; j2 += WAVE) {
             double2 v = s[j2];
             double2 x = x2[j2];
-            if (copy) d[j2] = v;
+            if (copy && i == L.M) d[j2] = v;      // only the reduced-cost row: the first pivot streams the rest from the parent (k_update)
             acc = fma(v.x, x.x, acc);
             acc = fma(v.y, x.y, acc);
         }
@@ -254,7 +257,8 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     const int r = best.i >> 1;
     const bool below = best.i & 1;
     const double sgn = below ? 1.0 : -1.0;
-    const double *row = T + (size_t)r * ld;
+    // (before its first pivot the solve still lives in the parent's tableau, see k_init)
+    const double *row = (Bv.iters[b] == 0 ? L.T + (size_t)Bv.src[b] * L.slotT : T) + (size_t)r * ld;
 
     // pass 0: row scale for the relative pivot tolerance
     double rmax = 0.0;
@@ -338,12 +342,16 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int it, i
     int slot = Bv.dst[b];
     double *T = L.T + (size_t)slot * L.slotT;
     double *beta = L.beta + (size_t)slot * L.Mp1p;
+    // first pivot of the solve (k_select has counted it): rows are read from the parent's slot and ALL of them are
+    // written to the new one; a refresh before any pivot reads the parent as well
+    const bool first = Bv.iters[b] == (mode == MODE_PIVOT ? 1 : 0) && Bv.src[b] != slot;
+    const double *Tin = first ? L.T + (size_t)Bv.src[b] * L.slotT : T;
     if (mode == MODE_REFRESH) {
         const double2 *x2 = reinterpret_cast<const double2 *>(L.xN + (size_t)slot * ld);
         for (int rr = wave; rr < tr; rr += NT / WAVE) {
             int i = tile * tr + rr;
             if (i >= L.Mp1) break;
-            const double2 *t2 = reinterpret_cast<const double2 *>(T + (size_t)i * ld);
+            const double2 *t2 = reinterpret_cast<const double2 *>(Tin + (size_t)i * ld);
             double acc = 0.0;
             for (int j2 = lane; j2 < ld2; j2 += WAVE) {
                 double2 v = t2[j2], x = x2[j2];
@@ -376,16 +384,19 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int it, i
         const bool has1 = i1 < L.Mp1;
         double2 *t0 = reinterpret_cast<double2 *>(T + (size_t)i0 * ld);
         double2 *t1 = reinterpret_cast<double2 *>(T + (size_t)(has1 ? i1 : i0) * ld);
+        const double2 *r0 = reinterpret_cast<const double2 *>(Tin + (size_t)i0 * ld);
+        const double2 *r1 = reinterpret_cast<const double2 *>(Tin + (size_t)(has1 ? i1 : i0) * ld);
         const bool piv0 = (i0 == d.r), piv1 = has1 && (i1 == d.r);
-        const double f0 = piv0 ? 0.0 : T[(size_t)i0 * ld + d.q] * d.p;
-        const double f1 = (!has1 || piv1) ? 0.0 : T[(size_t)i1 * ld + d.q] * d.p;
-        const bool do0 = piv0 || f0 != 0.0, do1 = has1 && (piv1 || f1 != 0.0);     // f == 0: row untouched by this pivot
+        const double f0 = piv0 ? 0.0 : Tin[(size_t)i0 * ld + d.q] * d.p;
+        const double f1 = (!has1 || piv1) ? 0.0 : Tin[(size_t)i1 * ld + d.q] * d.p;
+        // f == 0: row untouched by this pivot (but still to be copied when the solve leaves the parent's slot)
+        const bool do0 = first || piv0 || f0 != 0.0, do1 = has1 && (first || piv1 || f1 != 0.0);
         if (!do0 && !do1) continue;
         for (int j2 = lane; j2 < ld2; j2 += WAVE) {
             const double2 pr = p2[j2];
             double2 v0, v1;
-            if (do0 && !piv0) v0 = t0[j2];
-            if (do1 && !piv1) v1 = t1[j2];
+            if (do0 && !piv0) v0 = r0[j2];
+            if (do1 && !piv1) v1 = r1[j2];
             if (do0) {
                 if (piv0) { v0.x = -pr.x * d.p; v0.y = -pr.y * d.p; if (j2 == q2) { if (qodd) v0.y = d.p; else v0.x = d.p; } }
                 else { v0.x = fma(-f0, pr.x, v0.x); v0.y = fma(-f0, pr.y, v0.y); if (j2 == q2) { if (qodd) v0.y = f0; else v0.x = f0; } }
@@ -403,6 +414,25 @@ __global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int it, i
         }
     }
     __syncthreads();          // the pivot row in LDS is reused by the next work item
+    }
+}
+
+// ---- solves that ended without a pivot never left the parent's slot (see k_init): give them their own copy ----
+__global__ void k_list_unpivoted(BatchView Bv, int B, int slot_of_count)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && Bv.iters[b] == 0 && Bv.src[b] != Bv.dst[b]) Bv.work[atomicAdd(&Bv.nwork[slot_of_count], 1)] = b;
+}
+__global__ __launch_bounds__(NT) void k_copy_unpivoted(LpView L, BatchView Bv, int slot_of_count, int tiles)
+{
+    const int nitems = Bv.nwork[slot_of_count] * tiles;
+    const int ld2 = L.ld >> 1;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int b = Bv.work[item / tiles], tile = item % tiles;
+        const double2 *s = reinterpret_cast<const double2 *>(L.T + (size_t)Bv.src[b] * L.slotT);
+        double2 *d = reinterpret_cast<double2 *>(L.T + (size_t)Bv.dst[b] * L.slotT);
+        const int i0 = tile * TR, i1 = min(i0 + TR, L.M);            // row M is already there
+        for (size_t k = (size_t)i0 * ld2 + threadIdx.x; k < (size_t)i1 * ld2; k += NT) d[k] = s[k];
     }
 }
 
@@ -719,6 +749,12 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
         for (int b = 0; b < B; b++) if (h->status_h[b] == ST_RUNNING) h->active_h[running++] = b;
         if (running) HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, running * sizeof(int), hipMemcpyHostToDevice, s));
         if (chunk < 16) chunk *= 2;
+    }
+    {   // tableaux of the solves that made no pivot
+        const int cnt_slot = L.maxit + 40;
+        hipLaunchKernelGGL(k_list_unpivoted, dim3((B + 255) / 256), dim3(256), 0, s, bv, B, cnt_slot);
+        hipLaunchKernelGGL(k_copy_unpivoted, dim3(std::min(B * tiles, 2048)), dim3(NT), 0, s, L, bv, cnt_slot, tiles);
+        HIP_TRY(hipGetLastError());
     }
     if (status) for (int b = 0; b < B; b++) status[b] = h->status_h[b] == ST_RUNNING ? BSLV_LP_UNDEFINED : h->status_h[b];
     {
