@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""HBM traffic of the LP kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; collected separately, with
+--kernel-trace only, as MI355X_MICROARCH.md prescribes).  Units: rocprofv3 reports KB; on gfx950 FETCH_SIZE counts
+half of the bytes of wide coalesced reads and is doubled.
+usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <probe log with the pivot counts>"""
+import csv, json, re, sys, collections
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0]
+        acc[name][0] += float(r["Counter_Value"])
+        acc[name][1] += 1
+    return acc
+
+F = per_kernel(sys.argv[1], "FETCH_SIZE")
+W = per_kernel(sys.argv[2], "WRITE_SIZE")
+pivots = 0
+for line in open(sys.argv[3]):
+    m = re.search(r"pivots \[(\d+)\]", line)
+    if m:
+        pivots += int(m.group(1))
+    m = re.search(r"B=(\d+) ok=\d+ pivots/LP mean ([0-9.]+)", line)
+    if m:
+        pivots += round(int(m.group(1)) * float(m.group(2)))
+out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 scripts/lp_probe.py S-mid 256  (two separate passes)",
+       "units": "rocprofv3 reports KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE as is",
+       "workload": "S-mid P2 LPs 1011x506, batch 256, cold start + three warm-started batches (scripts/lp_probe.py); pivot count from the probe's own report (means rounded)",
+       "kernels": {k: {"fetch_KB_sum": round(F[k][0], 1), "launches": F[k][1], "write_KB_sum": round(W.get(k, [0, 0])[0], 1)} for k in F}}
+ku = "bslv::k_update"
+rd = 2.0 * F[ku][0] * 1024 / pivots
+wr = W[ku][0] * 1024 / pivots
+alg = 16.0 * (1000 + 5 + 1) * (500 + 2)
+out["k_update"] = {"pivots_in_run": pivots, "read_bytes_per_pivot_corrected": round(rd), "write_bytes_per_pivot": round(wr),
+                   "traffic_bytes_per_pivot": round(rd + wr), "algorithmic_bytes_per_pivot": round(alg), "traffic_over_algorithmic": round((rd + wr) / alg, 4)}
+print(json.dumps(out, indent=1))
