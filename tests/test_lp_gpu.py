@@ -83,3 +83,49 @@ def test_infeasible_and_unbounded_status():
     st, _ = eng.solve_batch([0], [0], np.zeros((1, 0)), np.zeros((1, 0)))
     assert st[0] == 1
     eng.close()
+
+
+def test_chains_of_warm_starts_through_unpivoted_slots(oracle):
+    """The engine does not copy the parent's tableau when a solve starts: the first pivot streams it into the new slot,
+    and a solve that ends without any pivot is copied afterwards.  Both kinds of slot must be complete tableaux: they
+    are used here as parents of a second generation (and that one of a third), objectives against the oracle."""
+    import oracle_api
+    prob = synth.covering_vlp(60, 30, 3, 5)
+    model = P2Model(prob)
+    rng = np.random.default_rng(5)
+    B = 48
+    V = _random_V(model, prob, rng, B)
+    V[B // 2:] = V[0]                       # half the batch repeats the bounds of the root solve: no pivot needed
+    ub = model.ub_for(V)
+    olp = oracle_api.OracleLP(model.L, model.lo, model.up, model.cost)
+
+    def oracle_obj(u):
+        for j in range(model.r):
+            olp.set_bound(model.var_first + j, -np.inf, u[j])
+        assert olp.solve(1) == 4
+        return olp.obj()
+
+    eng = LpEngine.from_model(model, pool_slots=3 * B + 1)
+    eng.reset_slot(0)
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+    assert st[0] == 4
+    gen1 = np.arange(1, B + 1, dtype=np.int32)
+    st, it1 = eng.solve_batch(np.zeros(B, np.int32), gen1, np.full((B, model.r), -np.inf), ub)
+    assert np.all(st == 4)
+    assert np.count_nonzero(np.asarray(it1) == 0) >= B // 2, "the repeated bounds were meant to need no pivot"
+    np.testing.assert_allclose(eng.obj(gen1), [oracle_obj(u) for u in ub], rtol=RTOL, atol=1e-9)
+    # second generation: every first-generation slot (pivoted or not) is a parent, bounds shuffled
+    perm = rng.permutation(B)
+    gen2 = np.arange(B + 1, 2 * B + 1, dtype=np.int32)
+    st, it2 = eng.solve_batch(gen1, gen2, np.full((B, model.r), -np.inf), ub[perm])
+    assert np.all(st == 4)
+    np.testing.assert_allclose(eng.obj(gen2), [oracle_obj(u) for u in ub[perm]], rtol=RTOL, atol=1e-9)
+    # third generation from the second, original bounds again
+    gen3 = np.arange(2 * B + 1, 3 * B + 1, dtype=np.int32)
+    st, it3 = eng.solve_batch(gen2, gen3, np.full((B, model.r), -np.inf), ub)
+    assert np.all(st == 4)
+    np.testing.assert_allclose(eng.obj(gen3), [oracle_obj(u) for u in ub], rtol=RTOL, atol=1e-9)
+    w = eng.dual(gen3, model.m, model.q)
+    y = eng.primal(gen3, model.M + model.n, model.q)
+    _check_identities(model, V, eng.obj(gen3), w, y)
+    olp.close()
