@@ -2011,7 +2011,7 @@ static int ensure_vcap(bslv_poly *h, int need)
     if ((rc = grow(&P.cls, h->nv, ncap, h->stream))) return rc;   // classes of the cut in flight survive a re-allocation
     if ((rc = grow(&P.inc_off, h->nv, ncap, h->stream))) return rc;
     if ((rc = grow(&P.inc_len, h->nv, ncap, h->stream))) return rc;
-    if ((rc = grow(&h->members, 0, ncap, h->stream))) return rc;
+    if ((rc = grow(&h->members, (size_t)P.cap, ncap, h->stream))) return rc;     // kept: a prune waiting for its fallback still needs its members
     {   // membership-bitmap slots: -1 everywhere except on the long elements of a hot chunk
         const int old = h->lslotcap;
         if ((rc = grow(&h->lslot_d, (size_t)old, (size_t)ncap, h->stream))) return rc;
@@ -2894,6 +2894,17 @@ int bslv_poly_set_batch_mode(bslv_poly *h, int mode)
     return 0;
 }
 long bslv_poly_rounds_run(const bslv_poly *h) { return h ? h->rounds_run : 0; }
+int bslv_poly_debug_set(bslv_poly *h, int key, long value)
+{
+    if (!h) return BSLV_E_ARG;
+    switch (key) {
+    case 0: h->k2_lds = (size_t)std::max(64L, value); return 0;       /* dynamic LDS of k2_fused (small: force the multi-kernel prune) */
+    case 1: h->speculate = value != 0; return 0;
+    case 2: h->hot_enabled = value != 0; return 0;
+    case 3: h->cross_ub = (int)std::max(0L, value); return 0;
+    default: return BSLV_E_ARG;
+    }
+}
 int bslv_poly_path_stats(const bslv_poly *h, long out[6])
 {
     if (!h || !out) return BSLV_E_ARG;

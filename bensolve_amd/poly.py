@@ -22,6 +22,8 @@ def _bind(lib):
     lib.bslv_poly_set_batch_mode.argtypes = [vp, i]
     lib.bslv_poly_rounds_run.argtypes = [vp]
     lib.bslv_poly_rounds_run.restype = ctypes.c_long
+    lib.bslv_poly_debug_set.argtypes = [vp, ctypes.c_int, ctypes.c_long]
+    lib.bslv_poly_debug_set.restype = ctypes.c_int
     lib.bslv_poly_path_stats.argtypes = [vp, vp]
     lib.bslv_poly_path_stats.restype = ctypes.c_int
     lib.bslv_poly_next.argtypes = [vp, vp, vp, vp, vp]
@@ -90,6 +92,9 @@ class PolyEngine:
 
     def rounds_run(self):
         return self.lib.bslv_poly_rounds_run(self.h)
+
+    def debug_set(self, key, value):
+        check(self.lib.bslv_poly_debug_set(self.h, int(key), int(value)))
 
     def path_stats(self):
         out = (ctypes.c_long * 6)()

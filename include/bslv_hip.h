@@ -114,6 +114,9 @@ long bslv_poly_rounds_run(const bslv_poly *h);
  * queued speculatively, [2] of those declined by the device and rerun, [3] prunes redone by the multi-kernel path,
  * [4] cuts applied one at a time, [5] reserved */
 int  bslv_poly_path_stats(const bslv_poly *h, long out[6]);
+/* test hook, same switches as the BSLV_* environment variables but at run time: key 0 dynamic LDS bytes of the one-workgroup
+ * prune (64 forces the multi-kernel prune), 1 speculative launch on/off, 2 hot mode on/off, 3 CROSS_UB */
+int  bslv_poly_debug_set(bslv_poly *h, int key, long value);
 int  bslv_poly_init(bslv_poly *h, int *rc_out);               /* poly__intl_apprx :153 */
 int  bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out); /* poly__get_vrtx :210 */
 int  bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count);

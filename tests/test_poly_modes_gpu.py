@@ -120,3 +120,66 @@ def test_chunk_modes_agree_bitwise(q, N, seed):
     do = O.dump()
     O.close()
     ph.assert_same(ph.canonical(do), ph.canonical(ref))
+
+
+def _smid_cut_sequence(steps):
+    """the dual vertices (cuts, in the order they were applied) of a batched Benson run on the bench workload"""
+    from bensolve_amd import synth
+    from bensolve_amd.benson import BensonEngine
+    prob = synth.CONFIGS["S-mid"]()
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=2 * 1024 + 64)
+    assert eng.start() == 0
+    for _ in range(steps):
+        nl, nt = eng.collect(1024, 0, 1)
+        rec, piv, ls = eng.solve_local(nl)
+        eng.apply(rec)
+    D = eng.poly_dump()
+    eng.close()
+    return prob["q"], np.ones(prob["q"]), D["Y"], D
+
+
+def test_smid_cut_sequence_matches_oracle_slotwise():
+    """~2000 real cuts of the bench workload (extreme directions with long incidence lists, degenerate points, facets of
+    10^2 elements), replayed one at a time through the engine and through oracle/poly_dd.c: slots, edges and incidence
+    lists bit for bit.  The replay settles every prune with the multi-kernel path in a second engine (all fallbacks)."""
+    q, c, Y, _ = _smid_cut_sequence(6)
+    O = ph.FlatPoly("oracle", q, 1, c)
+    for k in range(1, q + 1):
+        O.add(Y[k], 0)
+    assert O.init() == 0
+    for y in Y[q + 1:]:
+        O.add(y, 0)
+    do = O.dump()
+    O.close()
+    for force_multi in (False, True):
+        G = PolyEngine(q, 1, c)
+        G.set_batch_mode(0)
+        if force_multi:
+            G.debug_set(0, 64)
+        for k in range(1, q + 1):
+            G.add(Y[k], 0)
+        assert G.init() == 0
+        rest = Y[q + 1:]
+        for b0 in range(0, len(rest), 256):
+            G.add_cuts(rest[b0:b0 + 256], None)
+        dg = G.dump()
+        paths = G.path_stats()
+        G.close()
+        assert len(rest) > 1500 and paths["single_cuts"] > 1500
+        assert (paths["prune_fallbacks"] > 1500) == force_multi
+        for key in ("pu", "pi", "du", "di", "E", "I"):
+            assert np.array_equal(do[key], dg[key]), (force_multi, key)
+        live = do["pu"].astype(bool)
+        np.testing.assert_allclose(do["X"][live], dg["X"][live], rtol=1e-12, atol=1e-12)
+
+
+def test_smid_benson_steps_identical_in_all_modes():
+    """the batched driver on the bench workload: default mode, everything conservative, every prune through the fallback
+    (which exercises the abort / decline / rerun machinery on every cut) -- the same polyhedron bit for bit"""
+    dumps = {}
+    for name, env in (("default", {}), ("conservative", {"BSLV_NO_SPEC": "1", "BSLV_NO_HOT": "1"}), ("fallback_prune", {"BSLV_K2_LDS": "64"})):
+        with hooks(env):
+            dumps[name] = _smid_cut_sequence(5)[3]
+    for name in ("conservative", "fallback_prune"):
+        for key in ("pu", "pi", "ps", "X", "du", "di", "Y", "E", "I"):
+            assert np.array_equal(dumps[name][key], dumps["default"][key]), (name, key)
