@@ -38,7 +38,8 @@ if __name__ == "__main__":
         sys.exit(0)
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     res = {}
-    for name, env in (("default", {}), ("conservative", {"BSLV_NO_SPEC": "1", "BSLV_NO_HOT": "1"}), ("fallback_prune", {"BSLV_K2_LDS": "64"})):
+    for name, env in (("default", {}), ("conservative", {"BSLV_NO_SPEC": "1", "BSLV_NO_HOT": "1"}), ("fallback_prune", {"BSLV_K2_LDS": "64"}),
+                      ("decline", {"BSLV_CROSS_UB": "100"}), ("decline_fallback_nohot", {"BSLV_CROSS_UB": "100", "BSLV_K2_LDS": "64", "BSLV_NO_HOT": "1"})):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), str(steps), "child"], env=e, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
