@@ -37,6 +37,28 @@ def test_phase2_sets_match_oracle(m, n, q, seed, batch):
     assert tot["lps"] >= len(exp["X"]) - q
 
 
+@pytest.mark.parametrize("m,n,q,batch", [(24, 12, 3, 8), (60, 30, 3, 32), (60, 30, 4, 64), (120, 60, 4, 128)])
+def test_phase2_degenerate_family_matches_oracle(m, n, q, batch):
+    """BASELINE.json configs[4] (S-degenerate: unit cube + integer cover rows, integer lattice objectives, free columns) at
+    sizes the CPU oracle finishes: massively dual-degenerate LPs (ties in every ratio test, Bland's rule after the
+    stall limit) and an upper image whose vertices lie on many facets at once (the adjacency prune's hard case)."""
+    prob = synth.degenerate_vlp(m, n, q, 3)
+    eps = 1e-9
+    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=eps)
+    assert rc == 0
+    fp.dual_adjacency()
+    exp = ph.canonical(fp.dump(), decimals=6)
+    fp.close()
+    eng = BensonEngine(prob, eps=eps, pool_slots=max(4 * batch, 64))
+    assert eng.start() == 0
+    eng.run(batch)
+    eng.poly_call("dual_adjacency")
+    got = ph.canonical(eng.poly_dump(), decimals=6)
+    eng.close()
+    ph.assert_benson_results_agree(got, exp)
+    assert len(exp["X"]) >= 30
+
+
 import os
 import json
 
