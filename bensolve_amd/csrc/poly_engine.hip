@@ -1040,110 +1040,112 @@ __global__ __launch_bounds__(1024) void k_scan2(ScanArgs A)
 // its upper bound, so its place in the pool does not wait for the keep marks.
 // ne_dev != nullptr: the edge count of the previous cut is still on the device (its adjacent pairs were
 // appended without a host round trip); ne_ub then only sizes the grid.
-__global__ __launch_bounds__(PB) void k_flags2(PolyView P, const int2 *E, int ne_ub, const int *ne_dev, int nbe, int nv0, const int *counters,
-                                               unsigned char *eflag, int *ecount, Tri *ebsum, Tri *vbsum, ZMarks Z, unsigned long long *dbg)
+struct ZLocal { int n; int v[ZMAX]; };      // the long on-plane elements of a cut (ZMarks), fetched once per workgroup: uniform addresses
+__device__ __forceinline__ ZLocal zlocal_load(const ZMarks &Z, const int *counters)
 {
-    __shared__ Tri lds[16];
+    ZLocal z;
+    z.n = counters[3] < ZMAX ? counters[3] : ZMAX;
+#pragma unroll
+    for (int k = 0; k < ZMAX; k++) z.v[k] = Z.zlist[k];
+    return z;
+}
+// One edge of the flags pass: its flag (eflag), the list length of the new vertex of a crossing edge (ecount), the keep
+// marks / ZMarks stamps of a ZERO-PLUS edge (only once the cut is known to remove something: counters[0] = #MINUS).
+// Returns (survives, crosses, list length of the new vertex).  Classes are read through P.cls.
+__device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e, const int *counters, const ZLocal &zl, unsigned char *eflag, int *ecount,
+                                         const ZMarks &Z)
+{
     Tri t{0, 0, 0};
-    Tri tot;
-    __shared__ unsigned s_dbg[4];
-    if (dbg && threadIdx.x == 0) { s_dbg[0] = 0; s_dbg[1] = 0; s_dbg[2] = 0; s_dbg[3] = 0; }
-    const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
-    struct Fin { unsigned long long *dbg, t0; unsigned *sd; __device__ ~Fin() {
-        if (dbg && threadIdx.x == 0) {       // profiling aid (100 MHz ticks): slowest block; per-level latency of the slowest lane; first start / last end
-            const unsigned long long t1 = wall_clock64(), dt = t1 - t0;
-            atomicMax(&dbg[0], (dt << 32) | blockIdx.x);
-            for (int k = 0; k < 4; k++) atomicMax(&dbg[3 + k], (unsigned long long)sd[k]);
-            atomicMin(&dbg[12], t0); atomicMax(&dbg[13], t1);
-        } } } fin{dbg, t_start, s_dbg};
-    // blocks run back to front: the edges and elements the recent cuts created -- where the next cut acts, with the
-    // long dependent chains -- sit at the end of the arrays and must not wait for a second wave of workgroups
-    if ((int)blockIdx.x < nbe) {
-        const int eb = nbe - 1 - (int)blockIdx.x;
-        const int ne = ne_dev ? *ne_dev : ne_ub;
-        // the long on-plane elements of this cut (ZMarks), fetched up front: uniform addresses, off the per-edge chains
-        const int nzl = counters[3] < ZMAX ? counters[3] : ZMAX;
-        int zl[ZMAX];
+    const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
+    unsigned char f = 0;
+    if ((ca == -1 && cb == 1) || (ca == 1 && cb == -1)) { f = (ca == -1) ? 2 : 3; t.b = 1; }
+    else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = (ca == 0 || cb == 0) ? 4 : 1; t.a = 1; }
+    eflag[e] = f;
+    const bool cross = f == 2 || f == 3, mark = f == 4 && counters[0] > 0;
+    if (!(cross || mark)) return t;
+    // both need the intersection of the two incidence lists -- a crossing edge its size (the list of the new
+    // vertex), a ZERO-PLUS edge the positions in the ZERO element's list (its keep marks): one shared
+    // code path, so that a wave holding edges of both kinds does not walk two chains one after the other
+    const int ia = (mark && ca != 0) ? ed.y : ed.x, ib = ia == ed.x ? ed.y : ed.x;      // A = the ZERO element of a marking edge
+    const int na = P.inc_len[ia], nb = P.inc_len[ib];
+    int zid = -1;
+    if (mark && na > LONGN) {
 #pragma unroll
-        for (int k = 0; k < ZMAX; k++) zl[k] = Z.zlist[k];
-        const int e = eb * PB + threadIdx.x;
-        if (e < ne) {
-            const int2 ed = E[e];
-            const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
-            unsigned long long tq1 = 0, tq2 = 0, tq3 = 0;
-            if (dbg && (ca + cb < 2)) tq1 = wall_clock64();
-            unsigned char f = 0;
-            if ((ca == -1 && cb == 1) || (ca == 1 && cb == -1)) { f = (ca == -1) ? 2 : 3; t.b = 1; }
-            else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = (ca == 0 || cb == 0) ? 4 : 1; t.a = 1; }
-            eflag[e] = f;
-            const bool cross = f == 2 || f == 3, mark = f == 4 && counters[0] > 0;
-            if (cross || mark) {
-                // both need the intersection of the two incidence lists -- a crossing edge its size (the list of the new
-                // vertex), a ZERO-PLUS edge the positions in the ZERO element's list (its keep marks): one shared
-                // code path, so that a wave holding edges of both kinds does not walk two chains one after the other
-                const int ia = (mark && ca != 0) ? ed.y : ed.x, ib = ia == ed.x ? ed.y : ed.x;      // A = the ZERO element of a marking edge
-                const int na = P.inc_len[ia], nb = P.inc_len[ib];
-                if (dbg && na + nb > 0) tq2 = wall_clock64();
-                int zid = -1;
-                if (mark && na > LONGN) {
+        for (int k = 0; k < ZMAX; k++) if (k < zl.n && zl.v[k] == ia) zid = k;
+    }
+    if (zid >= 0 && nb <= LCAP) {
+        // ZERO element with a long list, PLUS end short: stamp the facets of the PLUS end in its ZMarks row
+        int RB[LCAP];
+        load_list(P.pool + P.inc_off[ib], nb, RB);
+        int *zrow = Z.rows + (size_t)zid * Z.stride;
 #pragma unroll
-                    for (int k = 0; k < ZMAX; k++) if (k < nzl && zl[k] == ia) zid = k;
-                }
-                if (zid >= 0 && nb <= LCAP) {
-                    // ZERO element with a long list, PLUS end short: stamp the facets of the PLUS end in its ZMarks row
-                    int RB[LCAP];
-                    load_list(P.pool + P.inc_off[ib], nb, RB);
-                    int *zrow = Z.rows + (size_t)zid * Z.stride;
-#pragma unroll
-                    for (int b2 = 0; b2 < LCAP; b2++) if (b2 < nb) zrow[RB[b2]] = Z.stamp;
-                } else if (na <= LCAP && nb <= LCAP) {
-                    int RA[LCAP], RB[LCAP];
-                    load_list(P.pool + P.inc_off[ia], na, RA); load_list(P.pool + P.inc_off[ib], nb, RB);
-                    unsigned m = match_mask(RA, na, RB);
-                    if (dbg && m + 1 > 0) tq3 = wall_clock64();
-                    if (cross) t.c = __popc(m) + 1;
-                    else {
-                        unsigned char *K = P.keep + P.inc_off[ia];
-                        while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // short list: plain stores, nothing to wait for
-                    }
-                } else {
-                    // one short list, one long list with a membership bitmap (hot mode): a bit test per short entry
-                    const bool ashort = na <= nb;
-                    const int is = ashort ? ia : ib, il = ashort ? ib : ia, ns = ashort ? na : nb;
-                    const unsigned *row = ns <= LONGN ? lrow(P, il) : nullptr;
-                    if (row && (cross || ashort)) {              // (a marking edge needs positions in the ZERO element's list: A short)
-                        int cnt = 0;
-                        for (int c0 = 0; c0 < ns; c0 += LCAP) {  // 16 entries at a time (a point on 17..64 facets takes a few rounds)
-                            const int nc = ns - c0 < LCAP ? ns - c0 : LCAP;
-                            int RS[LCAP];
-                            load_list(P.pool + P.inc_off[is] + c0, nc, RS);
-                            unsigned m = match_mask_bits(RS, nc, row);
-                            if (cross) cnt += __popc(m);
-                            else {
-                                unsigned char *K = P.keep + P.inc_off[ia] + c0;
-                                while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // plain stores, nothing to wait for
-                            }
-                        }
-                        if (cross) t.c = cnt + 1;
-                    } else if (cross) t.c = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
-                    else mark_keep(P, ed, Z, counters);
-                }
-                if (cross) ecount[e] = t.c;
-                if (dbg && tq3) {
-                    const unsigned long long tq4 = wall_clock64();
-                    atomicMax(&s_dbg[0], (unsigned)(tq1 - t_start)); atomicMax(&s_dbg[1], (unsigned)(tq2 - tq1));
-                    atomicMax(&s_dbg[2], (unsigned)(tq3 - tq2)); atomicMax(&s_dbg[3], (unsigned)(tq4 - tq3));
+        for (int b2 = 0; b2 < LCAP; b2++) if (b2 < nb) zrow[RB[b2]] = Z.stamp;
+    } else if (na <= LCAP && nb <= LCAP) {
+        int RA[LCAP], RB[LCAP];
+        load_list(P.pool + P.inc_off[ia], na, RA); load_list(P.pool + P.inc_off[ib], nb, RB);
+        unsigned m = match_mask(RA, na, RB);
+        if (cross) t.c = __popc(m) + 1;
+        else {
+            unsigned char *K = P.keep + P.inc_off[ia];
+            while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // short list: plain stores, nothing to wait for
+        }
+    } else {
+        // one short list, one long list with a membership bitmap (hot mode): a bit test per short entry
+        const bool ashort = na <= nb;
+        const int is = ashort ? ia : ib, il = ashort ? ib : ia, ns = ashort ? na : nb;
+        const unsigned *row = ns <= LONGN ? lrow(P, il) : nullptr;
+        if (row && (cross || ashort)) {              // (a marking edge needs positions in the ZERO element's list: A short)
+            int cnt = 0;
+            for (int c0 = 0; c0 < ns; c0 += LCAP) {  // 16 entries at a time (a point on 17..64 facets takes a few rounds)
+                const int nc = ns - c0 < LCAP ? ns - c0 : LCAP;
+                int RS[LCAP];
+                load_list(P.pool + P.inc_off[is] + c0, nc, RS);
+                unsigned m = match_mask_bits(RS, nc, row);
+                if (cross) cnt += __popc(m);
+                else {
+                    unsigned char *K = P.keep + P.inc_off[ia] + c0;
+                    while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // plain stores, nothing to wait for
                 }
             }
-        }
+            if (cross) t.c = cnt + 1;
+        } else if (cross) t.c = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
+        else mark_keep(P, ed, Z, counters);
+    }
+    if (cross) ecount[e] = t.c;
+    return t;
+}
+// Virtual workgroup vb of the (nbe + nbv) workgroups of a flags pass, executed by the calling workgroup (blockDim.x edges or
+// elements each).  Blocks run back to front: the edges and elements the recent cuts created -- where the next cut acts, with
+// the long dependent chains -- sit at the end of the arrays and must not wait for a second wave of workgroups.
+// accumulate: the edge sums are ADDED to ebsum (zeroed beforehand): another workgroup may own part of the same block.
+__device__ __forceinline__ void flags_block(const PolyView &P, const int2 *E, int ne, int nbe, int nbv, int nv0, const int *counters, unsigned char *eflag,
+                                            int *ecount, Tri *ebsum, Tri *vbsum, const ZMarks &Z, int vb, Tri *lds, bool accumulate)
+{
+    const int BS = blockDim.x;
+    Tri t{0, 0, 0};
+    Tri tot;
+    if (vb < nbe) {
+        const int eb = nbe - 1 - vb;
+        const ZLocal zl = zlocal_load(Z, counters);
+        const int e = eb * BS + threadIdx.x;
+        if (e < ne) t = flag_edge(P, E[e], e, counters, zl, eflag, ecount, Z);
         (void)block_exscan(t, &tot, lds);
-        if (threadIdx.x == 0) ebsum[eb] = tot;
+        if (threadIdx.x == 0) {
+            if (accumulate) { if (tot.a) atomicAdd(&ebsum[eb].a, tot.a); if (tot.b) atomicAdd(&ebsum[eb].b, tot.b); if (tot.c) atomicAdd(&ebsum[eb].c, tot.c); }
+            else ebsum[eb] = tot;
+        }
     } else {
-        const int b = (int)gridDim.x - 1 - (int)blockIdx.x, idx = b * PB + threadIdx.x;
+        const int b = nbe + nbv - 1 - vb, idx = b * BS + threadIdx.x;
         if (idx < vm_count(P, nv0)) { const int i = vm_id(P, idx); if (P.cls[i] == 0) { t.a = 1; t.c = P.inc_len[i] + 1; } }
         (void)block_exscan(t, &tot, lds);
         if (threadIdx.x == 0) vbsum[b] = tot;
     }
+}
+__global__ __launch_bounds__(1024) void k_flags2(PolyView P, const int2 *E, int ne_ub, const int *ne_dev, int nbe, int nv0, const int *counters,
+                                                 unsigned char *eflag, int *ecount, Tri *ebsum, Tri *vbsum, ZMarks Z)
+{
+    __shared__ Tri lds[16];
+    flags_block(P, E, ne_dev ? *ne_dev : ne_ub, nbe, (int)gridDim.x - nbe, nv0, counters, eflag, ecount, ebsum, vbsum, Z, (int)blockIdx.x, lds, false);
 }
 // emit pass.  Edge blocks: survivors -> Enew[0..nsurv), one new vertex per crossing edge (coordinates, flags,
 // incidence list, its edge to the PLUS end at Enew[nsurv + crossidx]).  Vertex blocks: MINUS elements leave,
@@ -1971,7 +1973,6 @@ struct bslv_poly {
     int *zlist = nullptr, *zrows = nullptr;     // ZMarks: CRING x ZMAX element ids, ZMAX x fcap facet stamps
     int pre_f = -1, pre_slot = 0, pre_nv = 0, pre_seq = 0;   // halfspace already classified (queued behind the previous cut's k_emit2)
     unsigned long long *k2dbg = nullptr;   // BSLV_K2_DEBUG=1: per-phase clock sums of k2_fused (100 MHz ticks), printed at destroy
-    unsigned long long *fdbg = nullptr; long nflagslaunch = 0;   // with BSLV_CUT_LOG: per-launch block timing of k_flags2
     FILE *cutlog = nullptr;           // BSLV_CUT_LOG=<file>: one line per cut (nv ne nminus nzero zero_ub nsurv ncross newlen), profiling aid
     PairBlk *blks = nullptr; int blkcap = 0;
     unsigned char *pflag = nullptr; size_t pflagcap = 0;
@@ -2319,8 +2320,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
                           h->pend_k2 ? (const Mail *)(h->k2mail_d + (h->pend_slot - 2)) : (const Mail *)nullptr};
         // (letting the last workgroup of k_flags2 do the scans -- ticket + fences -- was measured SLOWER than this
         // second launch: an agent-scope fence per workgroup writes the L2 back)
-        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, h->ecount, ebsum, vbsum, Z,
-                           h->fdbg ? h->fdbg + 16 * (h->nflagslaunch++ % 8192) : nullptr);
+        hipLaunchKernelGGL(k_flags2, dim3(nbe + nbv), dim3(PB), 0, s, h->P, h->E[h->ecur], ne_ub, ne_dev, nbe, nv0, counters, h->eflag, h->ecount, ebsum, vbsum, Z);
         const bool own_scan = spec && nbe + nbv <= 1024;      // few workgroups: k_emit2 sums the block sums itself, no scan launch
         if (!own_scan) hipLaunchKernelGGL(k_scan2, dim3(2), dim3(1024), 0, s, SA);
         auto tl1 = std::chrono::steady_clock::now();
@@ -2630,7 +2630,6 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
     if (const char *e = getenv("BSLV_CROSS_UB")) h->cross_ub = std::max(0, atoi(e));
     if (const char *e = getenv("BSLV_K2_LDS")) h->k2_lds = (size_t)std::max(64, atoi(e));      // test hook: a small value forces the multi-kernel prune
-    if (h->cutlog && getenv("BSLV_FLAGS_DEBUG") && hipMalloc(&h->fdbg, 8192 * 16 * sizeof(unsigned long long)) == hipSuccess) { std::vector<unsigned long long> z(8192 * 16, 0ull); for (int k = 0; k < 8192; k++) z[16 * k + 12] = ~0ull; (void)hipMemcpy(h->fdbg, z.data(), z.size() * 8, hipMemcpyHostToDevice); }
     if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
     // dual slot 0: "facet at infinity", ideal point (0,..,0,-1)  (bslv_poly.c:83-92)
@@ -2650,16 +2649,6 @@ void bslv_poly_destroy(bslv_poly *h)
                 h->hot_chunks ? (double)h->hot_elems / h->hot_chunks : 0.0, h->hot_chunks ? (double)h->hot_edges / h->hot_chunks : 0.0),
         fprintf(stderr, "poly host per cut (us): queue round A %.1f, k_emit2 %.1f, round B in all %.1f, mailbox wait %.1f\n", h->tm_launch[0] / std::max(1L, h->n_single), h->tm_launch[1] / std::max(1L, h->n_single),
                 h->tm_launch[2] / std::max(1L, h->n_single), h->tm_launch[3] / std::max(1L, h->n_single));
-    if (h->cutlog && h->fdbg) {
-        std::vector<unsigned long long> t(8192 * 16);
-        if (hipMemcpy(t.data(), h->fdbg, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
-            for (long k = 0; k < std::min<long>(h->nflagslaunch, 8192); k++)
-                { fprintf(h->cutlog, "F %ld %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", k, t[16 * k] >> 32, t[16 * k] & 0xffffffffull, t[16 * k + 1], t[16 * k + 2],
-                        t[16 * k + 3], t[16 * k + 4], t[16 * k + 5], t[16 * k + 6], t[16 * k + 7], t[16 * k + 8], t[16 * k + 9]);
-                fprintf(h->cutlog, "G %ld %llu %llu\n", k, t[16 * k + 10], t[16 * k + 11]);
-                  fprintf(h->cutlog, "H %ld %llu\n", k, t[16 * k + 13] - t[16 * k + 12]); }
-        (void)hipFree(h->fdbg);
-    }
     if (h->cutlog) fclose(h->cutlog);
     if (h->k2dbg) {
         unsigned long long t[16];
