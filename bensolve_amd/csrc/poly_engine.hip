@@ -37,8 +37,7 @@ struct PolyView {
     int d, cap;
     double *X;              // d x cap
     unsigned char *flag;    // cap
-    signed char *cls;       // cap: classes against the halfspace of the cut in progress
-    signed char *cls_nx;    // cap: classes against the NEXT halfspace, written by k_emit2 while it applies the current cut
+    signed char *cls;       // cap
     unsigned *inc_off;      // cap
     int *inc_len;           // cap
     int *pool;              // poolcap
@@ -1150,19 +1149,11 @@ __global__ __launch_bounds__(1024) void k_flags2(PolyView P, const int2 *E, int 
 // emit pass.  Edge blocks: survivors -> Enew[0..nsurv), one new vertex per crossing edge (coordinates, flags,
 // incidence list, its edge to the PLUS end at Enew[nsurv + crossidx]).  Vertex blocks: MINUS elements leave,
 // ZERO elements get their kept facets + the new one at pool[pool_z + prefix) and become members[0..nzero).
-// block-wide tally of the classes against the NEXT halfspace (the counters k_classify would produce): c in {-1, 0, 1, 2 = none},
-// len = incidence-list length of a ZERO element (its rebuilt-list bound is len + 1).  Every thread of the workgroup calls it.
-__device__ __forceinline__ void next_counts(signed char c, int len, int v, int *counters_n, int *zlist_n, Tri *lds)
-{
-    if (c == 0 && len > LONGN) { const int k = atomicAdd(&counters_n[3], 1); if (k < ZMAX) zlist_n[k] = v; }
-    const Tri s = block_sum(Tri{c == -1 ? 1 : 0, c == 0 ? 1 : 0, c == 0 ? len + 1 : 0}, lds);
-    if (threadIdx.x == 0 && (s.a | s.b)) { atomicAdd(&counters_n[0], s.a); atomicAdd(&counters_n[1], s.b); atomicAdd(&counters_n[2], s.c); }
-}
 template <int D>
 __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, const int2 *E, int ne_ub, const int *ne_dev, int nbe,
                                               const unsigned char *eflag, const int *ecount, const Tri *ebpre, const Tri *vbpre, const Tri *totals,
                                               int2 *Enew, int nv0, unsigned pool_e, unsigned pool_z, int *members, ZMarks Z, const int *counters, const CutDev *cd,
-                                              const int *EPold, int *EPnew, int own_scan, ScanArgs A, int do_next, Hp hn, int *counters_n, int *zlist_n)
+                                              const int *EPold, int *EPnew, int own_scan, ScanArgs A)
 {
     __shared__ Tri lds[16];
     Tri pre_e{0, 0, 0}, pre_v{0, 0, 0};
@@ -1201,12 +1192,10 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             else if (f >= 2) { t.b = 1; t.c = ecount[e]; }        // list length of the new vertex, from k_flags2
         }
         Tri ex = block_exscan(t, &tot, lds);
-        if (e >= ne) f = 0;              // (no early return: the workgroup still sums the next-cut counters together)
+        if (e >= ne) return;
         ex = tri_add(ex, own_scan ? pre_e : ebpre[eb]);
         if (!own_scan) nsurv_all = totals[0].a;
         const int d = D > 0 ? D : P.d;
-        signed char cn = 2;          // class of the vertex this thread creates against the next halfspace (2: none)
-        int wnew = -1, nlen = 0;
         if (f == 1 || f == 4) { Enew[ex.a] = ed; if (EPold) EPnew[ex.a] = EPold[e]; }      // (hot mode: where the edge sat before the chunk)
         else if (f == 2 || f == 3) {
             const int mi = (f == 2) ? ed.x : ed.y, pl = (f == 2) ? ed.y : ed.x;
@@ -1239,15 +1228,6 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             for (int k = 0; k < DD; k++) if (k < d) P.X[(size_t)k * P.cap + w] = fma(mu, dirv[k], base[k]);
             P.flag[w] = nf;
             P.cls[w] = 0;
-            if (do_next) {           // its class against the next halfspace, from the coordinates just computed (same fma chain as classify_one)
-                double sn = 0.0;
-#pragma unroll
-                for (int k = 0; k < DD; k++) if (k < d) sn = fma(hn.h[k], fma(mu, dirv[k], base[k]), sn);
-                const double an = (nf & F_IDEAL) ? 0.0 : hn.h[d];
-                cn = (sn > an + POLY_EPS) ? 1 : (sn > an - POLY_EPS ? 0 : -1);
-                P.cls_nx[w] = cn;
-                wnew = w;
-            }
             // incidence = inc(minus) & inc(plus) + new facet (bslv_poly.c:634-665)
             const unsigned off = pool_e + (unsigned)ex.c;
             int *out = P.pool + off;
@@ -1297,9 +1277,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             P.inc_len[w] = n;
             Enew[nsurv_all + ex.b] = int2{w, pl};
             if (EPold) EPnew[nsurv_all + ex.b] = -1;
-            nlen = n;
         }
-        if (do_next) next_counts(cn, nlen, wnew, counters_n, zlist_n, lds);
         return;
     }
     // ---- vertex blocks ----
@@ -1317,7 +1295,6 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
     ex = tri_add(ex, own_scan ? pre_v : vbpre[b]);
     const unsigned off_new = pool_z + (unsigned)ex.c;
     const bool longz = (c == 0) && n > LONGN;
-    int newlen = 0;
     {   // long lists (extreme directions): ordered compaction by the whole wave (ballot ranks), then the new facet
         unsigned long long todo = __ballot(longz);
         while (todo) {
@@ -1348,45 +1325,29 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
                 base += __popcll(bm);
             }
             if (lane == 0) { P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; if (lb) atomicOr(&lb[facet >> 5], 1u << (facet & 31)); }
-            if (lane == src) newlen = base + 1;
         }
     }
-    if (valid && c == -1) P.flag[i] &= ~F_USED;
-    if (valid && c == 0) {
-        members[ex.a] = i;
-        if (!longz) {
-            int m = 0;
-            if (n <= LCAP) {
-                int lst[LCAP];
-                unsigned keptmask = 0;
-                const unsigned char *K = P.keep + off_old;
-                load_list(P.pool + off_old, n, lst);
+    if (!valid) return;
+    if (c == -1) { P.flag[i] &= ~F_USED; return; }
+    if (c != 0) return;
+    members[ex.a] = i;
+    if (longz) return;
+    int m = 0;
+    if (n <= LCAP) {
+        int lst[LCAP];
+        unsigned keptmask = 0;
+        const unsigned char *K = P.keep + off_old;
+        load_list(P.pool + off_old, n, lst);
 #pragma unroll
-                for (int j = 0; j < LCAP; j++) { unsigned k = (j < n) ? K[j] : 0; keptmask |= (k & 1u) << j; }
+        for (int j = 0; j < LCAP; j++) { unsigned k = (j < n) ? K[j] : 0; keptmask |= (k & 1u) << j; }
 #pragma unroll
-                for (int j = 0; j < LCAP; j++) if ((keptmask >> j) & 1u) { P.pool[off_new + m++] = lst[j]; P.keep[off_old + j] = 0; }
-            } else
-                for (int j = 0; j < n; j++)
-                    if (P.keep[off_old + j]) { P.pool[off_new + m++] = P.pool[off_old + j]; P.keep[off_old + j] = 0; }
-            P.pool[off_new + m++] = facet;
-            P.inc_off[i] = off_new;
-            P.inc_len[i] = m;
-            newlen = m;
-        }
-    }
-    if (do_next) {
-        // classes of the surviving elements of this workgroup against the next halfspace (what k_classify would do in a
-        // launch of its own); list lengths are the rebuilt ones
-        signed char cn = 2;
-        int ln = 0;
-        if (valid && c != -1 && c != 2) {
-            const unsigned char fl = P.flag[i];
-            cn = classify_one(P, hn, i, fl);
-            if (cn == 0) ln = c == 0 ? newlen : P.inc_len[i];
-            P.cls_nx[i] = cn;
-        } else if (valid) P.cls_nx[i] = 2;
-        next_counts(cn, ln, i, counters_n, zlist_n, lds);
-    }
+        for (int j = 0; j < LCAP; j++) if ((keptmask >> j) & 1u) { P.pool[off_new + m++] = lst[j]; P.keep[off_old + j] = 0; }
+    } else
+        for (int j = 0; j < n; j++)
+            if (P.keep[off_old + j]) { P.pool[off_new + m++] = P.pool[off_old + j]; P.keep[off_old + j] = 0; }
+    P.pool[off_new + m++] = facet;
+    P.inc_off[i] = off_new;
+    P.inc_len[i] = m;
 }
 
 // ---- K2 in ONE workgroup: the adjacency prune over the members of the new facet (bslv_poly.c:482-540) ----
@@ -1702,7 +1663,7 @@ __global__ __launch_bounds__(PB) void k_hotv_emit(PolyView P, const int *tc, int
     __shared__ Tri lds[16];
     const int i = blockIdx.x * PB + threadIdx.x;
     Tri t{0, 0, 0};
-    if (i < nv) { t.a = (P.flag[i] & F_USED) && tc[i] > 0; if (!t.a) { P.cls[i] = 1; P.cls_nx[i] = 1; } }
+    if (i < nv) { t.a = (P.flag[i] & F_USED) && tc[i] > 0; if (!t.a) P.cls[i] = 1; }
     Tri tot;
     Tri ex = block_exscan(t, &tot, lds);
     if (t.a) hv[bpre[blockIdx.x].a + ex.a] = i;
@@ -2049,7 +2010,6 @@ static int ensure_vcap(bslv_poly *h, int need)
     int rc;
     if ((rc = grow(&P.flag, h->nv, ncap, h->stream, true))) return rc;
     if ((rc = grow(&P.cls, h->nv, ncap, h->stream))) return rc;   // classes of the cut in flight survive a re-allocation
-    if ((rc = grow(&P.cls_nx, h->nv, ncap, h->stream))) return rc;
     if ((rc = grow(&P.inc_off, h->nv, ncap, h->stream))) return rc;
     if ((rc = grow(&P.inc_len, h->nv, ncap, h->stream))) return rc;
     if ((rc = grow(&h->members, (size_t)P.cap, ncap, h->stream))) return rc;     // kept: a prune waiting for its fallback still needs its members
@@ -2231,13 +2191,7 @@ static int settle_k2(bslv_poly *h, bool *redo = nullptr)
 static int next_counter_slot(bslv_poly *h)
 {
     const int cslot = (int)(h->cutseq % CRING);
-    // entering a quarter of the ring clears the quarter two ahead for its next use: the slots of the cuts in flight (the current
-    // one and the pre-classified next one) are among the last few handed out, at least a quarter away from what is cleared
-    constexpr int QR = CRING / 4;
-    if (cslot % QR == 0 && h->cutseq > 0) {
-        int *ahead = h->counters + (size_t)(((cslot / QR + 2) % 4) * QR) * CSTRIDE;
-        if (hipMemsetAsync(ahead, 0, (size_t)QR * CSTRIDE * sizeof(int), h->stream) != hipSuccess) return -1;
-    }
+    if (cslot == 0 && h->cutseq > 0 && hipMemsetAsync(h->counters, 0, CRING * CSTRIDE * sizeof(int), h->stream) != hipSuccess) return -1;
     h->cutseq++;
     return cslot;
 }
@@ -2291,7 +2245,6 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         if ((rc = ensure_pool(h, (size_t)h->poolused + (size_t)h->cross_ub * 64))) return rc;
     }
     bool classified = h->pre_f == f && h->pre_nv == nv0;
-    if (classified) std::swap(h->P.cls, h->P.cls_nx);      // the classes k_emit2 of the previous cut (or a queued k_classify) left for this one
     int cslot = classified ? h->pre_slot : next_counter_slot(h);
     int cut_id = classified ? h->pre_seq : (int)h->cutseq;       // unique per classification: stamp of the ZMarks rows
     h->pre_f = -1;
@@ -2327,22 +2280,23 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         h->tm_launch[0] += std::chrono::duration<double, std::micro>(tl1 - tl0).count();
         if (spec) {
             // ---- round B, queued on the device's own verdict ----
-            spec_ns = -1;
-            if (next_f >= 0) {
-                if ((spec_ns = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-                h->pre_seq = (int)h->cutseq;
-            }
-            // k_emit2 also classifies the surviving and the new elements against the next halfspace (into cls_nx)
             launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne_ub, ne_dev, nbe, (const unsigned char *)h->eflag, (const int *)h->ecount, (const Tri *)ebsum, (const Tri *)vbsum,
                          (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, h->poolused, 0u, h->members, Z, (const int *)counters, (const CutDev *)cd,
-                         (const int *)h->EP[h->ecur], h->EP[1 - h->ecur], own_scan ? 1 : 0, SA, spec_ns >= 0 ? 1 : 0, hn, h->counters + CSTRIDE * std::max(spec_ns, 0), h->zlist + ZMAX * std::max(spec_ns, 0));
+                         (const int *)h->EP[h->ecur], h->EP[1 - h->ecur], own_scan ? 1 : 0, SA);
             auto tl2 = std::chrono::steady_clock::now();
             h->tm_launch[1] += std::chrono::duration<double, std::micro>(tl2 - tl1).count();
+            spec_ns = -1;
+            int ncb = 0;                       // workgroups of the prune launch that classify the next halfspace
+            if (next_f >= 0) {
+                if ((spec_ns = next_counter_slot(h)) < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
+                ncb = (vm_count(h->P, nv0) + h->cross_ub + K2T - 1) / K2T;
+                h->pre_seq = (int)h->cutseq;
+            }
             seqB = ++h->mailseq;
             slotB = 2 + (h->k2flip ^= 1);
-            hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
+            hipLaunchKernelGGL(k2_fused, dim3(1 + ncb), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
                                h->ne_dev, h->totals + 2, h->k2mail_d + (slotB - 2), seqB, h->k2dbg, (const CutDev *)cd, h->abort_d, h->EP[1 - h->ecur],
-                               hn, (int *)nullptr, (int *)nullptr);
+                               hn, h->counters + CSTRIDE * std::max(spec_ns, 0), h->zlist + ZMAX * std::max(spec_ns, 0));
         }
         auto tl3 = std::chrono::steady_clock::now();
         HIP_TRY(hipGetLastError());
@@ -2392,7 +2346,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         h->pend_k2 = true; h->pend_seq = seqB; h->pend_slot = slotB;
         h->pend_ebase = went ? nsurv + ncross : ne0;
         h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_nzero = nzero; h->pend_nv0 = nv0; h->pend_ncross = ncross;
-        if (spec_ns >= 0 && went) { h->pre_f = next_f; h->pre_slot = spec_ns; h->pre_nv = nv0 + ncross; }       // (a redundant cut runs no k_emit2: nothing classified)
+        if (spec_ns >= 0 && (went || nminus == 0)) { h->pre_f = next_f; h->pre_slot = spec_ns; h->pre_nv = went ? nv0 + ncross : nv0; }
     }
     if (nminus == 0) { h->fapplied[f] = 0; *rc_out = 1; return 0; }
     h->facet_of_rank.push_back(f);
@@ -2403,7 +2357,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         if ((rc = ensure_pool(h, (size_t)h->poolused + te.c + zero_ub))) return rc;
         launch_emit2(d, dim3(nbe + nbv), s, h->P, hp, rank, (const int2 *)h->E[h->ecur], ne0, (const int *)nullptr, nbe, (const unsigned char *)h->eflag, (const int *)h->ecount, (const Tri *)ebsum, (const Tri *)vbsum,
                      (const Tri *)(h->totals + 0), h->E[1 - h->ecur], nv0, pool_e, pool_z, h->members, Z, counters, (const CutDev *)nullptr,
-                     (const int *)h->EP[h->ecur], h->EP[1 - h->ecur], 0, ScanArgs{}, 0, hn, (int *)nullptr, (int *)nullptr);
+                     (const int *)h->EP[h->ecur], h->EP[1 - h->ecur], 0, ScanArgs{});
     }
     h->poolused += (unsigned)te.c + (unsigned)zero_ub;
     h->nv = nv0 + ncross;
@@ -2419,9 +2373,7 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             // classify the next halfspace now (the new vertices exist once k_emit2 has run; k2 does not read classes)
             const int ns = next_counter_slot(h);
             if (ns < 0) { set_error("hipMemsetAsync failed"); return BSLV_E_NODEVICE; }
-            PolyView Pn = h->P;
-            Pn.cls = h->P.cls_nx;                    // (consumed through the swap at the top of the next do_cut)
-            hipLaunchKernelGGL(k_classify, dim3((vm_count(h->P, h->nv) + PB - 1) / PB), dim3(PB), 0, s, Pn, hn, h->nv, h->counters + CSTRIDE * ns, h->zlist + ZMAX * ns, (const int *)nullptr);
+            hipLaunchKernelGGL(k_classify, dim3((vm_count(h->P, h->nv) + PB - 1) / PB), dim3(PB), 0, s, h->P, hn, h->nv, h->counters + CSTRIDE * ns, h->zlist + ZMAX * ns, (const int *)nullptr);
             h->pre_f = next_f; h->pre_slot = ns; h->pre_nv = h->nv; h->pre_seq = (int)h->cutseq;
         }
         if (nm >= 2) {
@@ -2658,7 +2610,7 @@ void bslv_poly_destroy(bslv_poly *h)
         (void)hipFree(h->k2dbg);
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
-    fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.cls_nx); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
+    fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
