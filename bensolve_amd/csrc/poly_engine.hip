@@ -2191,7 +2191,13 @@ static int settle_k2(bslv_poly *h, bool *redo = nullptr)
 static int next_counter_slot(bslv_poly *h)
 {
     const int cslot = (int)(h->cutseq % CRING);
-    if (cslot == 0 && h->cutseq > 0 && hipMemsetAsync(h->counters, 0, CRING * CSTRIDE * sizeof(int), h->stream) != hipSuccess) return -1;
+    // entering a quarter of the ring clears the quarter two ahead for its next use: the slots of the cuts in flight (the current
+    // one and the pre-classified next one) are among the last few handed out, at least a quarter away from what is cleared
+    constexpr int QR = CRING / 4;
+    if (cslot % QR == 0 && h->cutseq > 0) {
+        int *ahead = h->counters + (size_t)(((cslot / QR + 2) % 4) * QR) * CSTRIDE;
+        if (hipMemsetAsync(ahead, 0, (size_t)QR * CSTRIDE * sizeof(int), h->stream) != hipSuccess) return -1;
+    }
     h->cutseq++;
     return cslot;
 }
