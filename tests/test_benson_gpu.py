@@ -59,6 +59,26 @@ def test_phase2_degenerate_family_matches_oracle(m, n, q, batch):
     assert len(exp["X"]) >= 30
 
 
+def test_s_small_complete_run_matches_oracle():
+    """BASELINE.json configs[1] at full size, run to termination (2048 LPs per step, multi-cut rounds and single-cut
+    sequences mixed): the upper image of the batched GPU run and of the sequential CPU oracle agree as sets."""
+    prob = synth.CONFIGS["S-small"]()
+    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=1e-9)
+    assert rc == 0
+    fp.dual_adjacency()
+    exp = ph.canonical(fp.dump(), decimals=6)
+    fp.close()
+    eng = BensonEngine(prob, eps=1e-9, pool_slots=4 * 2048 + 64)
+    assert eng.start() == 0
+    eng.run(2048)
+    eng.poly_call("dual_adjacency")
+    got = ph.canonical(eng.poly_dump(), decimals=6)
+    paths = eng.poly_call("path_stats")
+    eng.close()
+    ph.assert_benson_results_agree(got, exp)
+    assert len(exp["X"]) > 5000 and paths["single_cuts"] > 100
+
+
 import os
 import json
 
