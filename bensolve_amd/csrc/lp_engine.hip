@@ -33,6 +33,7 @@ void set_error(const char *fmt, ...)
 constexpr int NS_L = 0, NS_U = 1, NS_F = 2, NS_S = 3;
 constexpr int ST_RUNNING = -1;
 constexpr int MODE_NONE = 0, MODE_PIVOT = 1, MODE_REFRESH = 2;
+constexpr int KP = 4;                  // pivots selected between two passes over the tableau (delayed update)
 constexpr int REFRESH_AFTER = 32;      // pivots of one solve after which optimality is only declared on a recomputed beta
 constexpr double TOL_BND = 1e-9, TOL_DJ = 1e-9, TOL_PIV = 1e-9;
 constexpr double BIG = 1e7;   // artificial bound for dual-infeasible free columns
@@ -53,8 +54,14 @@ struct BatchView {
     const int *src, *dst;
     const double *vlo, *vup;
     int *status, *iters, *mode, *verified;    // verified: bit 0 = beta is fresh, bit 1 = the solve started with a variable on an artificial bound
-    PivDesc *desc;
-    double *prow;
+    // Delayed update: up to KP pivots of an LP are SELECTED on vectors only (the pivot row and the entering column of the
+    // tableau as it would be after the pending pivots, the reduced-cost row dcur, beta) and then applied to the tableau in
+    // ONE pass (k_flush): a solve of <= KP pivots reads and writes its tableau once instead of once per pivot.
+    int *npend, *flushed;       // pending pivots of the LP; has the tableau of this solve been written to its own slot yet
+    PivDesc *desc;              // [B][KP]
+    double *prow;               // [B][KP][ld]   pivot rows as they were when chosen
+    double *pcol;               // [B][KP][Mp1p] multipliers f_i = (entering column)_i * p of every row i (0 for the pivot row)
+    double *dcur;               // [B][ld]       reduced-cost row of the LP, up to date
     int *work, *nwork;      // LPs whose tableau changes in this lock-step iteration (k_select -> k_update), count per iteration
 };
 
@@ -115,6 +122,10 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
         ns_d[j] = st;
         xN_d[j] = (st == NS_F) ? 0.0 : (st == NS_U ? up : lo);
     }
+    {   // working copy of the reduced-cost row (k_select keeps it up to date between passes over the tableau)
+        double *dc = Bv.dcur + (size_t)b * L.ld;
+        for (int j = threadIdx.x; j < L.ld; j += NT) dc[j] = j < L.N ? drow_s[j] : 0.0;
+    }
     dual_infeasible = __syncthreads_or(dual_infeasible);
     bigm = __syncthreads_or(bigm);
     if (threadIdx.x == 0) {
@@ -122,6 +133,8 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
         Bv.iters[b] = 0;
         Bv.mode[b] = MODE_NONE;
         Bv.verified[b] = 1 | (bigm ? 2 : 0);   // k_init recomputes beta from scratch
+        Bv.npend[b] = 0;
+        Bv.flushed[b] = src == dst;            // (in place: the slot already holds the tableau)
     }
 }
 
@@ -201,21 +214,41 @@ __device__ __forceinline__ double block_min(double v, double *sv)
 // ---- k_select: dual simplex choice of (leaving row r, entering column q) for each running LP.
 //      Same rules as oracle/lp_dense.c dual_simplex(): largest bound violation, Harris two-pass
 //      ratio test with the largest |pivot| among the ties. ----
-__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact, int it)
+// entry (i, j) of the tableau as it is after the pending pivots 0..np-1, given its value v0 in the stored tableau
+// (same operations, in the same order, as k_flush applies them -- and as one rank-1 update per pivot did)
+__device__ __forceinline__ double virt_entry(double v, int i, int j, int np, const PivDesc *pd, const double *prow, const double *pcol, int ld, int Mp1p)
+{
+    for (int s = 0; s < np; s++) {
+        const PivDesc d = pd[s];
+        if (i == d.r) v = j == d.q ? d.p : -prow[(size_t)s * ld + j] * d.p;
+        else { const double f = pcol[(size_t)s * Mp1p + i]; v = j == d.q ? f : fma(-f, prow[(size_t)s * ld + j], v); }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact)
 {
     __shared__ double sv[NT / WAVE];
     __shared__ int si[NT / WAVE];
+    __shared__ PivDesc s_d;
     if ((int)blockIdx.x >= nact) return;
     const int b = active[blockIdx.x];          // compacted list of the LPs still running
-    if (Bv.status[b] != ST_RUNNING) return;
+    if (Bv.status[b] != ST_RUNNING || Bv.mode[b] == MODE_REFRESH) return;
+    const int np = Bv.npend[b];
+    if (np >= KP) return;                      // waits for the pass over its tableau
     const int tid = threadIdx.x;
     int slot = Bv.dst[b];
-    double *T = L.T + (size_t)slot * L.slotT;
+    // the stored tableau of this solve: the parent's slot until the first pass has written its own (see k_init)
+    const double *T0 = L.T + (size_t)(Bv.flushed[b] ? slot : Bv.src[b]) * L.slotT;
     double *beta = L.beta + (size_t)slot * L.Mp1p;
     double *xN = L.xN + (size_t)slot * L.ld;
     int *bh = L.bh + (size_t)slot * L.M, *nh = L.nh + (size_t)slot * L.N;
     int *nstat = L.nstat + (size_t)slot * L.N, *pos = L.pos + (size_t)slot * (L.M + L.N);
     const int M = L.M, N = L.N, ld = L.ld;
+    const PivDesc *pd = Bv.desc + (size_t)b * KP;
+    double *prow0 = Bv.prow + (size_t)b * KP * ld;
+    double *pcol0 = Bv.pcol + (size_t)b * KP * L.Mp1p;
+    double *drow = Bv.dcur + (size_t)b * ld;
 
     // Phase A: leaving row = largest bound violation; id = 2*i + (below ? 1 : 0)
     // anti-cycling: after `bland_after` pivots (a healthy solve needs far fewer) switch to Bland's rule --
@@ -229,14 +262,13 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         if (!isinf(up)) { double v = bt - up; if (v > btol(up)) best = better_max(best, ValIdx{bland ? (double)(L.M + L.N - k) : v, 2 * i}); }
     }
     best = block_argmax(best, sv, si);
-    const double *drow = T + (size_t)M * ld;
     if (best.i < 0) {
         // recompute beta from scratch before concluding -- unless this solve made only a few pivots since k_init computed
         // it from scratch: the rank-1 updates of beta then carry ~1e-15 of error against tolerances of 1e-9, and the
-        // refresh is a full read of the tableau (4 MB per LP on S-mid, an eighth of the traffic of a 4-pivot solve)
+        // refresh is a full read of the tableau (4 MB per LP on S-mid)
         // (Not when the solve started on an artificial bound: values of 1e7 leave rounding debris of 1e-9 in beta.)
         if (!(Bv.verified[b] & 1) && (Bv.iters[b] > REFRESH_AFTER || (Bv.verified[b] & 2))) {
-            if (tid == 0) { Bv.mode[b] = MODE_REFRESH; Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b; }
+            if (tid == 0) Bv.mode[b] = MODE_REFRESH;          // k_flush applies what is pending and recomputes beta
             return;
         }
         // optimal for the bounded problem; unbounded if an artificial bound is active
@@ -257,8 +289,11 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     const int r = best.i >> 1;
     const bool below = best.i & 1;
     const double sgn = below ? 1.0 : -1.0;
-    // (before its first pivot the solve still lives in the parent's tableau, see k_init)
-    const double *row = (Bv.iters[b] == 0 ? L.T + (size_t)Bv.src[b] * L.slotT : T) + (size_t)r * ld;
+    // the pivot row as it is after the pending pivots, written where k_flush will read it
+    double *row = prow0 + (size_t)np * ld;
+    for (int j = tid; j < ld; j += NT)
+        row[j] = j < N ? virt_entry(T0[(size_t)r * ld + j], r, j, np, pd, prow0, pcol0, ld, L.Mp1p) : 0.0;
+    __syncthreads();
 
     // pass 0: row scale for the relative pivot tolerance
     double rmax = 0.0;
@@ -278,7 +313,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     th = block_min(th, sv);
     if (isinf(th)) {                      // no entering candidate: primal infeasible ...
         if (!(Bv.verified[b] & 1)) {      // ... unless the violation is rounding debris in beta: recompute it first
-            if (tid == 0) { Bv.mode[b] = MODE_REFRESH; Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b; }
+            if (tid == 0) Bv.mode[b] = MODE_REFRESH;
             return;
         }
         if (tid == 0) { Bv.status[b] = BSLV_LP_INFEASIBLE; Bv.mode[b] = MODE_NONE; }
@@ -296,9 +331,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     }
     piv = block_argmax(piv, sv, si);
     const int q = piv.i;
-    // Phase C: publish the pivot row (k_update overwrites row r in place) and the descriptor
-    double *prow = Bv.prow + (size_t)b * ld;
-    for (int j = tid; j < ld; j += NT) prow[j] = (j < N) ? row[j] : 0.0;
+    // Phase C: the descriptor, the basis heads
     if (tid == 0) {
         int kb = bh[r], kn = nh[q];
         double lo = LO(L, Bv, b, kb), up = UP(L, Bv, b, kb);
@@ -309,111 +342,115 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         d.r = r; d.q = q; d.p = 1.0 / trq;
         d.pbeta = br - target;
         d.enter_val = xN[q] + (target - br) / trq;
-        Bv.desc[b] = d;
+        Bv.desc[(size_t)b * KP + np] = d;
+        s_d = d;
         bh[r] = kn; nh[q] = kb;
         pos[kn] = r; pos[kb] = -1 - q;
         if (lo == up) { nstat[q] = NS_S; xN[q] = lo; }
         else if (below) { nstat[q] = NS_L; xN[q] = lo; }
         else { nstat[q] = NS_U; xN[q] = up; }
         Bv.mode[b] = MODE_PIVOT;
-        Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b;
         Bv.verified[b] &= 2;
         Bv.iters[b] += 1;
     }
+    __syncthreads();
+    const PivDesc d = s_d;
+    // Phase D: the entering column as it is after the pending pivots -> multipliers of all rows, beta; the reduced-cost row
+    double *pc = pcol0 + (size_t)np * L.Mp1p;
+    for (int i = tid; i <= M; i += NT) {
+        if (i == r) { pc[i] = 0.0; beta[i] = d.enter_val; continue; }
+        const double f = (i == M ? drow[q] : virt_entry(T0[(size_t)i * ld + q], i, q, np, pd, prow0, pcol0, ld, L.Mp1p)) * d.p;
+        pc[i] = f;
+        beta[i] = fma(-f, d.pbeta, beta[i]);
+    }
+    __syncthreads();
+    {
+        const double fM = pc[M];
+        for (int j = tid; j < N; j += NT) drow[j] = j == q ? fM : fma(-fM, row[j], drow[j]);
+    }
+    if (tid == 0) Bv.npend[b] = np + 1;
 }
 
-// ---- k_update: the HBM-bound kernel.  grid = (row tiles, LPs).  For every row i != r:
-//        f = T[i][q] * p ; T[i][j] -= f * prow[j] (j != q) ; T[i][q] = f ; beta[i] -= f * pbeta
-//      row r: T[r][j] = -prow[j] * p (j != q), T[r][q] = p, beta[r] = enter_val.
-//      Row M (reduced costs, objective value) is updated by the same formula.
-//      Algorithmic traffic: one read + one write of the tableau = 16 B per element per pivot. ----
-__global__ __launch_bounds__(NT) void k_update(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8, 16 or 32 */)
+// ---- which LPs need a pass over their tableau: pending pivots to apply, or beta to recompute ----
+__global__ void k_list_pending(BatchView Bv, const int *active, int nact, int it)
 {
-    extern __shared__ double s_prow[];
-    // persistent grid over the work items (LP of this iteration's work list x row tile): LPs that finished or did not
-    // pivot cost nothing -- with one workgroup per (LP, tile) of the whole batch, the later lock-step iterations spent
-    // most of their time dispatching workgroups that returned at once
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nact) return;
+    const int b = active[k];
+    if (Bv.npend[b] > 0 || Bv.mode[b] == MODE_REFRESH) Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b;
+}
+__global__ void k_after_flush(BatchView Bv, int it)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Bv.nwork[it]) return;
+    const int b = Bv.work[k];
+    Bv.npend[b] = 0;
+    Bv.flushed[b] = 1;
+    if (Bv.mode[b] == MODE_REFRESH) { Bv.verified[b] |= 1; Bv.mode[b] = MODE_NONE; }
+}
+
+// ---- k_flush: the HBM-bound kernel.  Persistent grid over (LP of the work list x row tile).  Every row of the stored
+//      tableau (the parent's slot on the first pass of a solve) is read once, the pending pivots are applied to it in order
+//        row r_s:  T[r][j] = -prow_s[j] * p_s (j != q_s),  T[r][q_s] = p_s
+//        others:   T[i][j] -= f_si * prow_s[j] (j != q_s), T[i][q_s] = f_si          (f_si from k_select)
+//      and the row is written to the LP's own slot; with MODE_REFRESH beta_i = T_i . xN is recomputed from the finished row.
+//      Algorithmic traffic of one pass: one read + one write of the tableau, whatever the number of pending pivots. ----
+__global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8, 16 or 32 */)
+{
+    extern __shared__ double s_rows[];           // KP pivot rows
+    __shared__ PivDesc s_pd[KP];
     const int nitems = Bv.nwork[it] * tiles;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = L.ld, ld2 = ld >> 1;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int b = Bv.work[item / tiles], tile = item % tiles;
-    const int mode = Bv.mode[b];
-    int slot = Bv.dst[b];
-    double *T = L.T + (size_t)slot * L.slotT;
-    double *beta = L.beta + (size_t)slot * L.Mp1p;
-    // first pivot of the solve (k_select has counted it): rows are read from the parent's slot and ALL of them are
-    // written to the new one; a refresh before any pivot reads the parent as well
-    const bool first = Bv.iters[b] == (mode == MODE_PIVOT ? 1 : 0) && Bv.src[b] != slot;
-    const double *Tin = first ? L.T + (size_t)Bv.src[b] * L.slotT : T;
-    if (mode == MODE_REFRESH) {
+        const int b = Bv.work[item / tiles], tile = item % tiles;
+        const int np = Bv.npend[b];
+        const bool refresh = Bv.mode[b] == MODE_REFRESH;
+        const int slot = Bv.dst[b];
+        const double *Tin = L.T + (size_t)(Bv.flushed[b] ? slot : Bv.src[b]) * L.slotT;
+        double *T = L.T + (size_t)slot * L.slotT;
+        double *beta = L.beta + (size_t)slot * L.Mp1p;
+        const double *pcol0 = Bv.pcol + (size_t)b * KP * L.Mp1p;
+        {
+            const double2 *g = reinterpret_cast<const double2 *>(Bv.prow + (size_t)b * KP * ld);
+            double2 *s2 = reinterpret_cast<double2 *>(s_rows);
+            for (int j2 = threadIdx.x; j2 < np * ld2; j2 += NT) s2[j2] = g[j2];
+            if (threadIdx.x < np) s_pd[threadIdx.x] = Bv.desc[(size_t)b * KP + threadIdx.x];
+        }
+        __syncthreads();
         const double2 *x2 = reinterpret_cast<const double2 *>(L.xN + (size_t)slot * ld);
+        const bool same = Tin == T;
         for (int rr = wave; rr < tr; rr += NT / WAVE) {
-            int i = tile * tr + rr;
+            const int i = tile * tr + rr;
             if (i >= L.Mp1) break;
-            const double2 *t2 = reinterpret_cast<const double2 *>(Tin + (size_t)i * ld);
+            double f[KP];
+            bool isr[KP], any = false;
+#pragma unroll
+            for (int s = 0; s < KP; s++) {
+                isr[s] = s < np && i == s_pd[s].r;
+                f[s] = (s < np && !isr[s]) ? pcol0[(size_t)s * L.Mp1p + i] : 0.0;
+                any |= isr[s] || f[s] != 0.0;
+            }
+            if (!any && same && !refresh) continue;               // row untouched by the pending pivots and already in place
+            const double2 *t_in = reinterpret_cast<const double2 *>(Tin + (size_t)i * ld);
+            double2 *t_out = reinterpret_cast<double2 *>(T + (size_t)i * ld);
             double acc = 0.0;
             for (int j2 = lane; j2 < ld2; j2 += WAVE) {
-                double2 v = t2[j2], x = x2[j2];
-                acc = fma(v.x, x.x, acc);
-                acc = fma(v.y, x.y, acc);
+                double2 v = t_in[j2];
+#pragma unroll
+                for (int s = 0; s < KP; s++) {
+                    if (s >= np) break;
+                    const double2 pr = reinterpret_cast<const double2 *>(s_rows + (size_t)s * ld)[j2];
+                    const int q2 = s_pd[s].q >> 1, qodd = s_pd[s].q & 1;
+                    if (isr[s]) { const double p = s_pd[s].p; v.x = -pr.x * p; v.y = -pr.y * p; if (j2 == q2) { if (qodd) v.y = p; else v.x = p; } }
+                    else { const double fs = f[s]; v.x = fma(-fs, pr.x, v.x); v.y = fma(-fs, pr.y, v.y); if (j2 == q2) { if (qodd) v.y = fs; else v.x = fs; } }
+                }
+                t_out[j2] = v;
+                if (refresh) { const double2 x = x2[j2]; acc = fma(v.x, x.x, acc); acc = fma(v.y, x.y, acc); }
             }
-            acc = wave_sum(acc);
-            if (lane == 0) beta[i] = acc;
+            if (refresh) { acc = wave_sum(acc); if (lane == 0) beta[i] = acc; }
         }
-        if (tile == 0 && threadIdx.x == 0) Bv.verified[b] |= 1;
-        continue;
-    }
-    const PivDesc d = Bv.desc[b];
-    {
-        const double2 *g = reinterpret_cast<const double2 *>(Bv.prow + (size_t)b * ld);
-        double2 *s = reinterpret_cast<double2 *>(s_prow);
-        for (int j2 = threadIdx.x; j2 < ld2; j2 += NT) s[j2] = g[j2];
-    }
-    __syncthreads();
-    const double2 *p2 = reinterpret_cast<const double2 *>(s_prow);
-    const int q2 = d.q >> 1, qodd = d.q & 1;
-    // each wave owns TR/4 consecutive rows and streams them two at a time: the multipliers f of both rows
-    // are fetched first, then both rows' loads are in flight before the first store (more bytes in
-    // flight per CU than one row at a time)
-    const int RPW = tr / (NT / WAVE);
-    const int row0 = tile * tr + wave * RPW;
-    for (int rr = 0; rr < RPW; rr += 2) {
-        const int i0 = row0 + rr, i1 = i0 + 1;
-        if (i0 >= L.Mp1) break;
-        const bool has1 = i1 < L.Mp1;
-        double2 *t0 = reinterpret_cast<double2 *>(T + (size_t)i0 * ld);
-        double2 *t1 = reinterpret_cast<double2 *>(T + (size_t)(has1 ? i1 : i0) * ld);
-        const double2 *r0 = reinterpret_cast<const double2 *>(Tin + (size_t)i0 * ld);
-        const double2 *r1 = reinterpret_cast<const double2 *>(Tin + (size_t)(has1 ? i1 : i0) * ld);
-        const bool piv0 = (i0 == d.r), piv1 = has1 && (i1 == d.r);
-        const double f0 = piv0 ? 0.0 : Tin[(size_t)i0 * ld + d.q] * d.p;
-        const double f1 = (!has1 || piv1) ? 0.0 : Tin[(size_t)i1 * ld + d.q] * d.p;
-        // f == 0: row untouched by this pivot (but still to be copied when the solve leaves the parent's slot)
-        const bool do0 = first || piv0 || f0 != 0.0, do1 = has1 && (first || piv1 || f1 != 0.0);
-        if (!do0 && !do1) continue;
-        for (int j2 = lane; j2 < ld2; j2 += WAVE) {
-            const double2 pr = p2[j2];
-            double2 v0, v1;
-            if (do0 && !piv0) v0 = r0[j2];
-            if (do1 && !piv1) v1 = r1[j2];
-            if (do0) {
-                if (piv0) { v0.x = -pr.x * d.p; v0.y = -pr.y * d.p; if (j2 == q2) { if (qodd) v0.y = d.p; else v0.x = d.p; } }
-                else { v0.x = fma(-f0, pr.x, v0.x); v0.y = fma(-f0, pr.y, v0.y); if (j2 == q2) { if (qodd) v0.y = f0; else v0.x = f0; } }
-                t0[j2] = v0;
-            }
-            if (do1) {
-                if (piv1) { v1.x = -pr.x * d.p; v1.y = -pr.y * d.p; if (j2 == q2) { if (qodd) v1.y = d.p; else v1.x = d.p; } }
-                else { v1.x = fma(-f1, pr.x, v1.x); v1.y = fma(-f1, pr.y, v1.y); if (j2 == q2) { if (qodd) v1.y = f1; else v1.x = f1; } }
-                t1[j2] = v1;
-            }
-        }
-        if (lane == 0) {
-            if (do0) beta[i0] = piv0 ? d.enter_val : fma(-f0, d.pbeta, beta[i0]);
-            if (do1) beta[i1] = piv1 ? d.enter_val : fma(-f1, d.pbeta, beta[i1]);
-        }
-    }
-    __syncthreads();          // the pivot row in LDS is reused by the next work item
+        __syncthreads();          // the pivot rows in LDS are reused by the next work item
     }
 }
 
@@ -485,6 +522,7 @@ struct bslv_lpq {
     int Bcap = 0;
     int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
     int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
+    int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
     int upd_grid = 32768;             // workgroups of the persistent k_update (BSLV_UPD_GRID; 1024..32768 measured equal within 2 %)    // work list of a lock-step iteration, its length per iteration
     int *active_d = nullptr, *active_h = nullptr;       // compacted indices of the LPs still running (device / pinned)
     double *vlo_d = nullptr, *vup_d = nullptr, *prow_d = nullptr, *out_d = nullptr;
@@ -505,7 +543,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     int cap = std::max(B, h->Bcap * 2);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d); fr(h->work_d);
-    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
     h->Bcap = 0;
@@ -519,8 +557,12 @@ static int ensure_batch(bslv_lpq *h, int B)
     size_t vc = (size_t)std::max(1, h->L.vcnt);
     HIP_TRY(hipMalloc(&h->vlo_d, cap * vc * sizeof(double)));
     HIP_TRY(hipMalloc(&h->vup_d, cap * vc * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->prow_d, (size_t)cap * h->L.ld * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->desc_d, cap * sizeof(PivDesc)));
+    HIP_TRY(hipMalloc(&h->prow_d, (size_t)cap * KP * h->L.ld * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->desc_d, (size_t)cap * KP * sizeof(PivDesc)));
+    HIP_TRY(hipMalloc(&h->pcol_d, (size_t)cap * KP * h->L.Mp1p * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->dcur_d, (size_t)cap * h->L.ld * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->npend_d, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->flushed_d, cap * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->status_h, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->active_d, cap * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->active_h, cap * sizeof(int)));
@@ -533,7 +575,7 @@ static BatchView bview(bslv_lpq *h)
     BatchView v;
     v.src = h->src_d; v.dst = h->dst_d; v.vlo = h->vlo_d; v.vup = h->vup_d;
     v.status = h->status_d; v.iters = h->iters_d; v.mode = h->mode_d; v.verified = h->ver_d;
-    v.desc = h->desc_d; v.prow = h->prow_d;
+    v.desc = h->desc_d; v.prow = h->prow_d; v.pcol = h->pcol_d; v.dcur = h->dcur_d; v.npend = h->npend_d; v.flushed = h->flushed_d;
     v.work = h->work_d; v.nwork = h->nwork_d;
     return v;
 }
@@ -642,7 +684,7 @@ void bslv_lpq_destroy(bslv_lpq *h)
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
-    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
     for (auto &e : h->evpool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -699,7 +741,7 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     int rc;
     if ((rc = ensure_batch(h, B))) return rc;
     LpView &L = h->L;
-    if ((size_t)L.ld * sizeof(double) > 64 * 1024) { set_error("row too long for the LDS-staged pivot row (N=%d)", L.N); return BSLV_E_CAPACITY; }
+    if ((size_t)KP * L.ld * sizeof(double) > 64 * 1024) { set_error("rows too long for the LDS-staged pivot rows (N=%d)", L.N); return BSLV_E_CAPACITY; }
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
     HIP_TRY(hipMemcpyAsync(h->src_d, src, B * sizeof(int), hipMemcpyHostToDevice, s));
@@ -719,15 +761,18 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(NT), 0, s, L, bv, B);
     hipLaunchKernelGGL(k_init, dim3(tiles, B), dim3(NT), 0, s, L, bv, B);
     HIP_TRY(hipGetLastError());
-    const size_t lds = (size_t)L.ld * sizeof(double);
-    int it = 0, chunk = 4, running = B;
+    const size_t lds = (size_t)KP * L.ld * sizeof(double);
+    // One ROUND = KP lock-step selections on vectors, then one pass over the tableaux of the LPs that have something
+    // pending (k_flush).  The status vector is read back every 1, 2, 4, ... rounds.
+    int it = 0, chunk = 1, running = B;
     for (int b = 0; b < B; b++) h->active_h[b] = b;
     HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, B * sizeof(int), hipMemcpyHostToDevice, s));
     size_t nev = 0;
     h->last_update_ms = 0;
     while (running > 0 && it < L.maxit + 8) {
         for (int c = 0; c < chunk; c++, it++) {
-            hipLaunchKernelGGL(k_select, dim3(running), dim3(NT), 0, s, L, bv, h->active_d, running, it);
+            for (int lev = 0; lev < KP; lev++) hipLaunchKernelGGL(k_select, dim3(running), dim3(NT), 0, s, L, bv, h->active_d, running);
+            hipLaunchKernelGGL(k_list_pending, dim3((running + 255) / 256), dim3(256), 0, s, bv, h->active_d, running, it);
             if (h->profile) {
                 if (nev == h->evpool.size()) {
                     hipEvent_t a, b2;
@@ -739,8 +784,9 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
             // few LPs left: smaller row tiles keep >= ~2k workgroups in flight
             const int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : 8);
             const int ntile = (L.Mp1 + tr - 1) / tr;
-            hipLaunchKernelGGL(k_update, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), lds, s, L, bv, it, ntile, tr);
+            hipLaunchKernelGGL(k_flush, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), lds, s, L, bv, it, ntile, tr);
             if (h->profile) { HIP_TRY(hipEventRecord(h->evpool[nev].second, s)); nev++; }
+            hipLaunchKernelGGL(k_after_flush, dim3((running + 255) / 256), dim3(256), 0, s, bv, it);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->status_h, h->status_d, B * sizeof(int), hipMemcpyDeviceToHost, s));
