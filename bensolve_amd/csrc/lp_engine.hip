@@ -33,7 +33,7 @@ void set_error(const char *fmt, ...)
 constexpr int NS_L = 0, NS_U = 1, NS_F = 2, NS_S = 3;
 constexpr int ST_RUNNING = -1;
 constexpr int MODE_NONE = 0, MODE_PIVOT = 1, MODE_REFRESH = 2;
-constexpr int KP = 4;                  // pivots selected between two passes over the tableau (delayed update)
+constexpr int KP = 6;                  // pivots selected between two passes over the tableau (delayed update; 4: 3.4 ms, 6: 3.0, 8: 3.1 ms per S-mid batch)
 constexpr int REFRESH_AFTER = 32;      // pivots of one solve after which optimality is only declared on a recomputed beta
 constexpr double TOL_BND = 1e-9, TOL_DJ = 1e-9, TOL_PIV = 1e-9;
 constexpr double BIG = 1e7;   // artificial bound for dual-infeasible free columns
@@ -523,6 +523,7 @@ struct bslv_lpq {
     int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
     int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
+    size_t flush_lds_max = 64 * 1024;  // dynamic LDS k_flush may use (raised to 144 KB at create when the runtime allows)
     int upd_grid = 32768;             // workgroups of the persistent k_update (BSLV_UPD_GRID; 1024..32768 measured equal within 2 %)    // work list of a lock-step iteration, its length per iteration
     int *active_d = nullptr, *active_h = nullptr;       // compacted indices of the LPs still running (device / pinned)
     double *vlo_d = nullptr, *vup_d = nullptr, *prow_d = nullptr, *out_d = nullptr;
@@ -673,6 +674,13 @@ int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double 
     }
     if ((rc = upload_bounds(h, lb, ub))) return fail(rc);
     if ((rc = ensure_batch(h, 64))) return fail(rc);
+    {   // k_flush stages KP pivot rows in LDS: wide problems (N > ~1300) need more than the default 64 KB
+        const size_t want = (size_t)KP * h->L.ld * sizeof(double);
+        if (want > h->flush_lds_max) {
+            if (want <= 144 * 1024 && hipFuncSetAttribute((const void *)k_flush, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) h->flush_lds_max = want;
+            else (void)hipGetLastError();
+        }
+    }
     *out = h;
     return 0;
 }
@@ -741,7 +749,7 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     int rc;
     if ((rc = ensure_batch(h, B))) return rc;
     LpView &L = h->L;
-    if ((size_t)KP * L.ld * sizeof(double) > 64 * 1024) { set_error("rows too long for the LDS-staged pivot rows (N=%d)", L.N); return BSLV_E_CAPACITY; }
+    if ((size_t)KP * L.ld * sizeof(double) > h->flush_lds_max) { set_error("rows too long for the LDS-staged pivot rows (N=%d)", L.N); return BSLV_E_CAPACITY; }
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
     HIP_TRY(hipMemcpyAsync(h->src_d, src, B * sizeof(int), hipMemcpyHostToDevice, s));
