@@ -12,9 +12,10 @@ torch.distributed.run, one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
   setup (untimed): problem generation, upload, cold start + the r weighted-sum LPs, and the ramp
               of the vertex queue up to one full batch -- so every timed step has full batches and
               all inputs (constraint matrix, tableau pool, polyhedron) are resident in HBM.
-  roofline  = the tableau-update kernel (k_update): algorithmic bytes = pivots * 16*(m+r+1)*(n+2)
-              (one read + one write of the eliminated tableau) / its HIP-event time,
-              measured live inside the timed region on the engine's stream.
+  roofline  = the tableau pass (k_flush): algorithmic bytes = (LP, pass) pairs * 16*(m+r+1)*(n+2)
+              (one read + one write of the eliminated tableau per pass; SURVEY 8d K3 charges that per pivot,
+              the engine applies up to 6 pivots per pass) / its HIP-event time, measured live inside the
+              timed region on the engine's stream.
   cpu_baseline = the CPU oracle (oracle/benson_cpu.c: sequential loop, warm-started dense dual
               simplex, 1 core) on the first LPs of the same workload, rank 0, N=1 only.
 """
@@ -121,7 +122,7 @@ def main():
     rounds0 = eng.poly_call("rounds_run")
     nv0 = eng.poly_call("counts")["new_vertices"]
     pt0 = eng.poly_call("counts")["pair_tests"]
-    lps = cuts = pivots = lockstep = redundant = confirmed = 0
+    lps = cuts = pivots = lockstep = redundant = confirmed = passes = 0
     upd_ms = 0.0
     lp_ms = 0.0
     sync()
@@ -137,6 +138,7 @@ def main():
         ls = eng.lp_call("last_stats")
         upd_ms += ls["update_ms"]
         lp_ms += ls["total_ms"]
+        passes += ls["passes"]
     sync()
     dt = time.perf_counter() - t0
     eng.lp_call("set_profile", False)
@@ -157,21 +159,27 @@ def main():
     else:
         pivots_all = pivots
 
-    alg_bytes_per_pivot = 16.0 * (m + r + 1) * (n + 2)          # SURVEY 8d K3 / BASELINE.md 3.4
+    # Dominant kernel: k_flush, one pass over the tableau of every LP that has pivots pending (delayed update: up to 6 pivots
+    # are selected on vectors, then applied together).  Unit = one (LP, pass); algorithmic bytes per unit = one read + one
+    # write of the eliminated tableau, 16*(m+r+1)*(n+2) -- SURVEY 8d K3's figure, which the reference algorithm pays per PIVOT.
+    alg_bytes_per_pass = 16.0 * (m + r + 1) * (n + 2)
     launches = max(lockstep, 1)
-    achieved = (pivots * alg_bytes_per_pivot) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
-    # HBM traffic from the PMC counters: collected in separate rocprofv3 --pmc passes (profiles/r01_pmc_k_update.json,
-    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per pivot; scaled to this run's pivots per launch
+    achieved = (passes * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    per_pivot_equiv = (pivots * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    # HBM traffic from the PMC counters: collected in separate rocprofv3 --pmc passes (profiles/r01_pmc_k_flush.json,
+    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per tableau pass; scaled to this run's passes per launch
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_k_update.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_k_flush.json")
     if args.workload == "S-mid" and os.path.exists(pmc_file):
-        per_pivot = json.load(open(pmc_file))["k_update"]["traffic_bytes_per_pivot"]
-        traffic = round(per_pivot * pivots / launches, 0)
-    roofline = {"bound": "hbm", "kernel": "k_update (tableau rank-1 update)", "achieved": round(achieved, 1), "peak": 8000.0,
+        per_pass = json.load(open(pmc_file))["k_flush"]["traffic_bytes_per_pass"]
+        traffic = round(per_pass * passes / launches, 0)
+    roofline = {"bound": "hbm", "kernel": "k_flush (tableau pass applying the pending pivots)", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "launches": launches, "avg_launch_us": round(upd_ms * 1e3 / launches, 2),
-                "alg_bytes_per_launch": round(pivots * alg_bytes_per_pivot / launches, 0),
-                "pivots_rank0": pivots}
+                "alg_bytes_per_launch": round(passes * alg_bytes_per_pass / launches, 0),
+                "tableau_passes_rank0": passes, "pivots_rank0": pivots, "pivots_per_pass": round(pivots / max(passes, 1), 2),
+                "per_pivot_equivalent_GBps": round(per_pivot_equiv, 1),
+                "note": "per_pivot_equivalent = what one read+write of the tableau PER PIVOT (SURVEY 8d K3, the reference's GLPK-style update) would need to move in the same time"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

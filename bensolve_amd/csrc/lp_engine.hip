@@ -523,6 +523,7 @@ struct bslv_lpq {
     int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
     int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
+    long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
     size_t flush_lds_max = 64 * 1024;  // dynamic LDS k_flush may use (raised to 144 KB at create when the runtime allows)
     int upd_grid = 32768;             // workgroups of the persistent k_update (BSLV_UPD_GRID; 1024..32768 measured equal within 2 %)    // work list of a lock-step iteration, its length per iteration
     int *active_d = nullptr, *active_h = nullptr;       // compacted indices of the LPs still running (device / pinned)
@@ -804,6 +805,13 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
         if (running) HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, running * sizeof(int), hipMemcpyHostToDevice, s));
         if (chunk < 16) chunk *= 2;
     }
+    {   // tableau passes of this batch: sum of the work-list lengths of the rounds
+        std::vector<int> nw(std::max(it, 1), 0);
+        if (it > 0) HIP_TRY(hipMemcpy(nw.data(), h->nwork_d, (size_t)it * sizeof(int), hipMemcpyDeviceToHost));
+        long passes = 0;
+        for (int k = 0; k < it; k++) passes += nw[k];
+        h->last_passes = passes;
+    }
     {   // tableaux of the solves that made no pivot
         const int cnt_slot = L.maxit + 40;
         hipLaunchKernelGGL(k_list_unpivoted, dim3((B + 255) / 256), dim3(256), 0, s, bv, B, cnt_slot);
@@ -875,6 +883,7 @@ int bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out)
     return 0;
 }
 
+long bslv_lpq_last_passes(const bslv_lpq *h) { return h ? h->last_passes : 0; }
 int bslv_lpq_last_stats(const bslv_lpq *h, int *lockstep_iters, long *pivots, double *update_ms, double *total_ms)
 {
     if (!h) return BSLV_E_ARG;

@@ -143,4 +143,6 @@ class LpEngine:
         ums = ctypes.c_double()
         tms = ctypes.c_double()
         check(self.lib.bslv_lpq_last_stats(self.h, ctypes.byref(it), ctypes.byref(piv), ctypes.byref(ums), ctypes.byref(tms)))
-        return dict(lockstep_iters=it.value, pivots=piv.value, update_ms=ums.value, total_ms=tms.value)
+        self.lib.bslv_lpq_last_passes.restype = ctypes.c_long
+        self.lib.bslv_lpq_last_passes.argtypes = [ctypes.c_void_p]
+        return dict(lockstep_iters=it.value, pivots=piv.value, update_ms=ums.value, total_ms=tms.value, passes=self.lib.bslv_lpq_last_passes(self.h))

@@ -85,6 +85,10 @@ int  bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out);
 /* when on, every tableau-update launch is bracketed by HIP events on the engine's stream */
 int  bslv_lpq_set_profile(bslv_lpq *h, int on);
 int  bslv_lpq_last_stats(const bslv_lpq *h, int *lockstep_iters, long *pivots, double *update_ms, double *total_ms);
+/* lockstep_iters = rounds (each: up to KP selections on vectors + one pass of k_flush over the tableaux with pending pivots);
+ * update_ms = time in k_flush (HIP events, with set_profile).  Tableau passes of the last batch, i.e. how many (LP, round)
+ * pairs k_flush read and wrote: */
+long bslv_lpq_last_passes(const bslv_lpq *h);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Polyhedron engine  (replaces bslv_poly.h:90-118)

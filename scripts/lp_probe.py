@@ -19,7 +19,8 @@ v0 = np.zeros((1, q))
 eng.reset_slot(0)
 t = time.time()
 st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), model.ub_for(v0))
-print("cold start: status", st, "pivots", it, "time %.3f s" % (time.time() - t), eng.last_stats(), flush=True)
+ls0 = eng.last_stats()
+print("cold start: status", st, "pivots", it, "passes %d" % ls0["passes"], "time %.3f s" % (time.time() - t), ls0, flush=True)
 y0 = eng.primal([0], model.y_first, q)[0]
 z0 = eng.obj([0])[0]
 print("y0", y0, "z0", z0)
@@ -32,7 +33,7 @@ for scale in (0.01, 0.1, 1.0):
     dt = time.time() - t
     s = eng.last_stats()
     piv = s["pivots"]
-    bytes_alg = piv * 16.0 * (model.M + 1) * (model.N + 1)
-    print("scale %.2f: B=%d ok=%d pivots/LP mean %.1f max %d lockstep %d total %.1f ms update %.1f ms -> %.0f LPs/s, update-kernel %.0f GB/s (alg), wall %.0f GB/s"
-          % (scale, B, int((st == 4).sum()), it.mean(), it.max(), s["lockstep_iters"], dt * 1e3, s["update_ms"],
-             B / dt, bytes_alg / (s["update_ms"] * 1e-3) / 1e9, bytes_alg / dt / 1e9), flush=True)
+    bytes_pass = s["passes"] * 16.0 * (model.M + 1) * (model.N + 1)         # one read + one write of the tableau per (LP, pass)
+    print("scale %.2f: B=%d ok=%d pivots/LP mean %.1f max %d rounds %d passes %d pivots %d total %.1f ms flush %.1f ms -> %.0f LPs/s, k_flush %.0f GB/s (tableau passes), %.0f GB/s per-pivot equivalent"
+          % (scale, B, int((st == 4).sum()), it.mean(), it.max(), s["lockstep_iters"], s["passes"], piv, dt * 1e3, s["update_ms"],
+             B / dt, bytes_pass / (s["update_ms"] * 1e-3) / 1e9, bytes_pass / max(s["passes"], 1) * piv / (s["update_ms"] * 1e-3) / 1e9), flush=True)
