@@ -1072,13 +1072,17 @@ __device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e
 #pragma unroll
         for (int k = 0; k < ZMAX; k++) if (k < zl.n && zl.v[k] == ia) zid = k;
     }
-    if (zid >= 0 && nb <= LCAP) {
-        // ZERO element with a long list, PLUS end short: stamp the facets of the PLUS end in its ZMarks row
-        int RB[LCAP];
-        load_list(P.pool + P.inc_off[ib], nb, RB);
+    if (zid >= 0 && nb <= LONGN) {
+        // ZERO element with a long list, PLUS end of up to 64 facets: stamp the facets of the PLUS end in its ZMarks row,
+        // 16 at a time (independent loads; one entry after the other cost 10 us per edge on points with 17..64 facets)
         int *zrow = Z.rows + (size_t)zid * Z.stride;
+        for (int c0 = 0; c0 < nb; c0 += LCAP) {
+            const int nc = nb - c0 < LCAP ? nb - c0 : LCAP;
+            int RB[LCAP];
+            load_list(P.pool + P.inc_off[ib] + c0, nc, RB);
 #pragma unroll
-        for (int b2 = 0; b2 < LCAP; b2++) if (b2 < nb) zrow[RB[b2]] = Z.stamp;
+            for (int b2 = 0; b2 < LCAP; b2++) if (b2 < nc) zrow[RB[b2]] = Z.stamp;
+        }
     } else if (na <= LCAP && nb <= LCAP) {
         int RA[LCAP], RB[LCAP];
         load_list(P.pool + P.inc_off[ia], na, RA); load_list(P.pool + P.inc_off[ib], nb, RB);
@@ -1312,6 +1316,26 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
             int base = 0;
+            constexpr int LIT = 16;                     // lists of up to 1024 facets: all entries and all marks are fetched first
+            if (nn <= LIT * WAVE) {                     // (two memory latencies in all instead of two per 64 entries)
+                int g[LIT];
+                bool k[LIT];
+#pragma unroll
+                for (int it = 0; it < LIT; it++) { const int j = it * WAVE + lane; g[it] = j < nn ? P.pool[oo + j] : 0; }
+#pragma unroll
+                for (int it = 0; it < LIT; it++) { const int j = it * WAVE + lane; k[it] = j < nn && (row ? row[g[it]] == Z.stamp : P.keep[oo + j] != 0); }
+#pragma unroll
+                for (int it = 0; it < LIT; it++) {
+                    if (it * WAVE >= nn) break;
+                    const unsigned long long bm = __ballot(k[it]);
+                    if (k[it]) {
+                        P.pool[on + base + __popcll(bm & ((1ull << lane) - 1ull))] = g[it];
+                        if (!row) P.keep[oo + it * WAVE + lane] = 0;
+                        if (lb) atomicOr(&lb[g[it] >> 5], 1u << (g[it] & 31));
+                    }
+                    base += __popcll(bm);
+                }
+            } else
             for (int j0 = 0; j0 < nn; j0 += WAVE) {
                 const int j = j0 + lane;
                 const int g = j < nn ? P.pool[oo + j] : 0;
