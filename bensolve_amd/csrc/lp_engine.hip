@@ -11,9 +11,10 @@
 //   xN    ld doubles: values of the nonbasic variables (padding = 0)
 //   bh[M], nh[N] basis heads (variable ids: 0..M-1 aux, M..M+N-1 structural)
 //   nstat[N] nonbasic status, pos[M+N] (row if basic, -1-col if nonbasic)
-// One lock-step iteration = k_select (one workgroup per LP: leaving row, Harris ratio test,
-// pivot row copied to a side buffer) + k_update (grid = row tiles x LPs: rank-1 update, pure
-// HBM streaming: reads and writes every tableau element once -> 16 B per element per pivot).
+// One ROUND of the lock-step loop = KP x k_select (one workgroup per LP: leaving row, Harris ratio test on the tableau as it
+// would be after the pivots still pending -- rebuilt from the stored tableau and the pending (pivot row, multipliers) pairs)
+// + k_flush (persistent grid over (LP, row tile): pure HBM streaming, every tableau element read once, all pending pivots
+// applied to it in order, written once -> 16 B per element per ROUND instead of per pivot).
 #include "common.h"
 #include <vector>
 #include <algorithm>
@@ -37,7 +38,7 @@ constexpr int KP = 6;                  // pivots selected between two passes ove
 constexpr int REFRESH_AFTER = 32;      // pivots of one solve after which optimality is only declared on a recomputed beta
 constexpr double TOL_BND = 1e-9, TOL_DJ = 1e-9, TOL_PIV = 1e-9;
 constexpr double BIG = 1e7;   // artificial bound for dual-infeasible free columns
-constexpr int TR = 32;        // tableau rows per workgroup in k_update / k_init
+constexpr int TR = 32;        // tableau rows per workgroup in k_flush / k_init
 constexpr int NT = 256;       // threads per workgroup
 
 struct PivDesc { int r, q; double p, pbeta, enter_val; };
@@ -62,7 +63,7 @@ struct BatchView {
     double *prow;               // [B][KP][ld]   pivot rows as they were when chosen
     double *pcol;               // [B][KP][Mp1p] multipliers f_i = (entering column)_i * p of every row i (0 for the pivot row)
     double *dcur;               // [B][ld]       reduced-cost row of the LP, up to date
-    int *work, *nwork;      // LPs whose tableau changes in this lock-step iteration (k_select -> k_update), count per iteration
+    int *work, *nwork;      // LPs whose tableau k_flush passes over in a round (k_list_pending), their number per round
 };
 
 __device__ __forceinline__ double LO(const LpView &L, const BatchView &Bv, int b, int k)
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
 
 // ---- k_init: beta_dst = T_src . xN_dst, one wave per row, and the reduced-cost row T_dst[M] = T_src[M].  The rest of the
 //      parent's tableau is NOT copied here: the first pivot of the solve reads the parent and writes the new slot
-//      (k_update), which saves one write and one read of the tableau per LP; solves without a pivot are copied by
+//      (k_flush), which saves one write and one read of the tableau per LP; solves without a pivot are copied by
 //      k_copy_unpivoted at the end. ----
 __global__ __launch_bounds__(NT) void k_init(LpView L, BatchView Bv, int B)
 {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(NT) void k_init(LpView L, BatchView Bv, int B)
         for (int j2 = lane; j2 < ld2; j2 += WAVE) {
             double2 v = s[j2];
             double2 x = x2[j2];
-            if (copy && i == L.M) d[j2] = v;      // only the reduced-cost row: the first pivot streams the rest from the parent (k_update)
+            if (copy && i == L.M) d[j2] = v;      // only the reduced-cost row: the first pass streams the rest from the parent (k_flush)
             acc = fma(v.x, x.x, acc);
             acc = fma(v.y, x.y, acc);
         }
@@ -525,7 +526,7 @@ struct bslv_lpq {
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
     size_t flush_lds_max = 64 * 1024;  // dynamic LDS k_flush may use (raised to 144 KB at create when the runtime allows)
-    int upd_grid = 32768;             // workgroups of the persistent k_update (BSLV_UPD_GRID; 1024..32768 measured equal within 2 %)    // work list of a lock-step iteration, its length per iteration
+    int upd_grid = 32768;             // workgroups of the persistent k_flush (BSLV_UPD_GRID; 1024..32768 measured equal within 2 %)
     int *active_d = nullptr, *active_h = nullptr;       // compacted indices of the LPs still running (device / pinned)
     double *vlo_d = nullptr, *vup_d = nullptr, *prow_d = nullptr, *out_d = nullptr;
     size_t out_cap = 0;
