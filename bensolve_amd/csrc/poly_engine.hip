@@ -1051,9 +1051,11 @@ __device__ __forceinline__ ZLocal zlocal_load(const ZMarks &Z, const int *counte
 // One edge of the flags pass: its flag (eflag), the list length of the new vertex of a crossing edge (ecount), the keep
 // marks / ZMarks stamps of a ZERO-PLUS edge (only once the cut is known to remove something: counters[0] = #MINUS).
 // Returns (survives, crosses, list length of the new vertex).  Classes are read through P.cls.
+struct LongStamp { const int *list; int n; int *zrow; };       // facets of a long PLUS end still to be stamped in a ZMarks row (by the whole wave)
 __device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e, const int *counters, const ZLocal &zl, unsigned char *eflag, int *ecount,
-                                         const ZMarks &Z)
+                                         const ZMarks &Z, LongStamp &ls)
 {
+    ls.n = 0;
     Tri t{0, 0, 0};
     const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
     unsigned char f = 0;
@@ -1083,6 +1085,10 @@ __device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e
 #pragma unroll
             for (int b2 = 0; b2 < LCAP; b2++) if (b2 < nc) zrow[RB[b2]] = Z.stamp;
         }
+    } else if (zid >= 0) {
+        // both ends are extreme directions: hundreds of facets to stamp -- left to the whole wave (flags_block); one lane
+        // walking the list cost 15-40 us on every cut that has a direction on the hyperplane
+        ls.list = P.pool + P.inc_off[ib]; ls.n = nb; ls.zrow = Z.rows + (size_t)zid * Z.stride;
     } else if (na <= LCAP && nb <= LCAP) {
         int RA[LCAP], RB[LCAP];
         load_list(P.pool + P.inc_off[ia], na, RA); load_list(P.pool + P.inc_off[ib], nb, RB);
@@ -1131,7 +1137,20 @@ __device__ __forceinline__ void flags_block(const PolyView &P, const int2 *E, in
         const int eb = nbe - 1 - vb;
         const ZLocal zl = zlocal_load(Z, counters);
         const int e = eb * BS + threadIdx.x;
-        if (e < ne) t = flag_edge(P, E[e], e, counters, zl, eflag, ecount, Z);
+        LongStamp ls{nullptr, 0, nullptr};
+        if (e < ne) t = flag_edge(P, E[e], e, counters, zl, eflag, ecount, Z, ls);
+        {   // long lists to stamp: all lanes of the wave share each one
+            const int lane = threadIdx.x & 63;
+            unsigned long long todo = __ballot(ls.n > 0);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int *L = (const int *)__shfl((unsigned long long)(uintptr_t)ls.list, src, WAVE);
+                int *zr = (int *)__shfl((unsigned long long)(uintptr_t)ls.zrow, src, WAVE);
+                const int n = __shfl(ls.n, src, WAVE);
+                for (int j = lane; j < n; j += WAVE) zr[L[j]] = Z.stamp;
+            }
+        }
         (void)block_exscan(t, &tot, lds);
         if (threadIdx.x == 0) {
             if (accumulate) { if (tot.a) atomicAdd(&ebsum[eb].a, tot.a); if (tot.b) atomicAdd(&ebsum[eb].b, tot.b); if (tot.c) atomicAdd(&ebsum[eb].c, tot.c); }
