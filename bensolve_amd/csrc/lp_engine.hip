@@ -44,7 +44,7 @@ constexpr int NT = 256;       // threads per workgroup
 struct PivDesc { int r, q; double p, pbeta, enter_val; };
 
 struct LpView {
-    int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit, bland_after;
+    int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit, bland_after, trace;
     size_t slotT;
     double *T, *beta, *xN;
     int *bh, *nh, *nstat, *pos;
@@ -227,11 +227,21 @@ __device__ __forceinline__ double virt_entry(double v, int i, int j, int np, con
     return v;
 }
 
-__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact)
+// BFRT = bound flipping ("long step") ratio test, compiled in when the LP has boxed variables: the dual step passes the
+// breakpoints of boxed candidates -- they switch to their other bound instead of entering the basis -- for as long as the
+// leaving row stays infeasible.  Without it every boxed column with a zero reduced cost costs one degenerate pivot
+// (hypercube rows of S-degenerate: hundreds of thousands).  cap2 = capacity of the candidate arrays in dynamic LDS.
+template <bool BFRT>
+__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact, int cap2)
 {
     __shared__ double sv[NT / WAVE];
     __shared__ int si[NT / WAVE];
     __shared__ PivDesc s_d;
+    __shared__ int s_cnt, s_nboxed, s_stop;
+    extern __shared__ unsigned char dyn_sel[];
+    double *skey = reinterpret_cast<double *>(dyn_sel);          // [cap2] breakpoints |d_j| / |alpha_j| of the candidates
+    int *sidx = reinterpret_cast<int *>(skey + cap2);             // [cap2] their columns
+    unsigned char *sflag = reinterpret_cast<unsigned char *>(sidx + cap2);   // [N] 1 = column switches bound in this iteration
     if ((int)blockIdx.x >= nact) return;
     const int b = active[blockIdx.x];          // compacted list of the LPs still running
     if (Bv.status[b] != ST_RUNNING || Bv.mode[b] == MODE_REFRESH) return;
@@ -301,11 +311,73 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     for (int j = tid; j < N; j += NT) rmax = fmax(rmax, fabs(row[j]));
     rmax = block_max(rmax, sv);
     const double ptol = TOL_PIV * (1.0 + rmax);
+    int nflip = 0;
+    if constexpr (BFRT) {
+        // candidates with their breakpoints; anything to flip at all?
+        if (tid == 0) { s_cnt = 0; s_nboxed = 0; s_stop = 0; }
+        for (int j = tid; j < N; j += NT) sflag[j] = 0;
+        __syncthreads();
+        for (int j = tid; j < N; j += NT) {
+            int st = nstat[j];
+            if (st == NS_S) continue;
+            double a = sgn * row[j];
+            if (fabs(a) < ptol) continue;
+            if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F))) {
+                const int at = atomicAdd(&s_cnt, 1);
+                skey[at] = fabs(drow[j]) / fabs(a);
+                sidx[at] = j;
+                const int k = nh[j];
+                const double lo = LO(L, Bv, b, k), up = UP(L, Bv, b, k);
+                if (st != NS_F && !isinf(lo) && !isinf(up) && !L.art[k]) atomicAdd(&s_nboxed, 1);
+            }
+        }
+        __syncthreads();
+        const int C = s_cnt;
+        if (s_nboxed > 0) {
+            int n2 = 2;
+            while (n2 < C) n2 <<= 1;
+            for (int i = C + tid; i < n2; i += NT) { skey[i] = INFINITY; sidx[i] = 0x7fffffff; }
+            __syncthreads();
+            // bitonic sort by (breakpoint, column): the order, and with it every decision below, is unique
+            for (int kk = 2; kk <= n2; kk <<= 1)
+                for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                    for (int i = tid; i < n2; i += NT) {
+                        const int x = i ^ jj;
+                        if (x > i) {
+                            const double ka = skey[i], kb2 = skey[x];
+                            const int ia = sidx[i], ib = sidx[x];
+                            const bool gt = ka > kb2 || (ka == kb2 && ia > ib);
+                            if (((i & kk) == 0) == gt) { skey[i] = kb2; skey[x] = ka; sidx[i] = ib; sidx[x] = ia; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            if (tid == 0) {
+                // walk the breakpoints: a boxed candidate switches bound while the row stays infeasible after its switch
+                const int kb0 = bh[r];
+                double slope = below ? LO(L, Bv, b, kb0) - beta[r] : beta[r] - UP(L, Bv, b, kb0);
+                int k = 0;
+                for (; k < C; k++) {
+                    const int j = sidx[k], kv = nh[j];
+                    const double lo = LO(L, Bv, b, kv), up = UP(L, Bv, b, kv);
+                    if (nstat[j] == NS_F || isinf(lo) || isinf(up) || L.art[kv]) break;
+                    const double dec = (up - lo) * fabs(row[j]);
+                    if (slope - dec < 0.0) break;
+                    slope -= dec;
+                    sflag[j] = 1;
+                }
+                s_stop = k;
+            }
+            __syncthreads();
+            nflip = s_stop;
+        }
+    }
     // pass 1: Harris bound on the dual step
     double th = INFINITY;
     for (int j = tid; j < N; j += NT) {
         int st = nstat[j];
         if (st == NS_S) continue;
+        if (BFRT && sflag[j]) continue;
         double a = sgn * row[j];
         if (fabs(a) < ptol) continue;
         if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
@@ -325,6 +397,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     for (int j = tid; j < N; j += NT) {
         int st = nstat[j];
         if (st == NS_S) continue;
+        if (BFRT && sflag[j]) continue;
         double a = sgn * row[j];
         if (fabs(a) < ptol) continue;
         if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
@@ -332,6 +405,15 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     }
     piv = block_argmax(piv, sv, si);
     const int q = piv.i;
+    if constexpr (BFRT) {
+        // the switches: other bound, other status.  beta no longer matches xN: this pivot is applied at once and beta
+        // recomputed from the new tableau (MODE_REFRESH below), before the LP selects again
+        for (int k = tid; k < nflip; k += NT) {
+            const int j = sidx[k], kv = nh[j];
+            if (nstat[j] == NS_L) { nstat[j] = NS_U; xN[j] = UP(L, Bv, b, kv); }
+            else { nstat[j] = NS_L; xN[j] = LO(L, Bv, b, kv); }
+        }
+    }
     // Phase C: the descriptor, the basis heads
     if (tid == 0) {
         int kb = bh[r], kn = nh[q];
@@ -350,7 +432,9 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         if (lo == up) { nstat[q] = NS_S; xN[q] = lo; }
         else if (below) { nstat[q] = NS_L; xN[q] = lo; }
         else { nstat[q] = NS_U; xN[q] = up; }
-        Bv.mode[b] = MODE_PIVOT;
+        if (L.trace == b && (Bv.iters[b] < 300 || Bv.iters[b] % 997 == 0)) printf("lp %d it %d r %d (var %d, %s by %.3e) q %d (var %d) alpha %.3e d %.3e step %.3e flips %d obj %.12g%s\n", b, Bv.iters[b], r, kb, below ? "below" : "above",
+                                 below ? lo - br : br - up, q, kn, trq, drow[q], fabs(drow[q] / trq), nflip, beta[M], bland ? " bland" : "");
+        Bv.mode[b] = nflip > 0 ? MODE_REFRESH : MODE_PIVOT;
         Bv.verified[b] &= 2;
         Bv.iters[b] += 1;
     }
@@ -525,6 +609,8 @@ struct bslv_lpq {
     int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
+    size_t select_lds_max = 64 * 1024; // dynamic LDS of k_select<true> (candidate sort of the bound flipping ratio test)
+    bool has_boxed = false;            // some variable outside the per-LP range has two finite, non-artificial bounds
     size_t flush_lds_max = 64 * 1024;  // dynamic LDS k_flush may use (raised to 144 KB at create when the runtime allows)
     int upd_grid = 32768;             // workgroups of the persistent k_flush (BSLV_UPD_GRID; 1024..32768 measured equal within 2 %)
     int *active_d = nullptr, *active_h = nullptr;       // compacted indices of the LPs still running (device / pinned)
@@ -596,6 +682,8 @@ static int upload_bounds(bslv_lpq *h, const double *lb, const double *ub)
         if (c > 0 && std::isinf(lo[k])) { lo[k] = -BIG; art[k] |= 1; }
         if (c < 0 && std::isinf(up[k])) { up[k] = BIG; art[k] |= 2; }
     }
+    h->has_boxed = false;
+    for (int k = 0; k < M + N; k++) if (!art[k] && std::isfinite(lo[k]) && std::isfinite(up[k]) && lo[k] < up[k]) h->has_boxed = true;
     HIP_TRY(hipMemcpyAsync(h->lb_d, lo.data(), (M + N) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->ub_d, up.data(), (M + N) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->art_d, art.data(), (M + N), hipMemcpyHostToDevice, h->stream));
@@ -772,6 +860,19 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     hipLaunchKernelGGL(k_init, dim3(tiles, B), dim3(NT), 0, s, L, bv, B);
     HIP_TRY(hipGetLastError());
     const size_t lds = (size_t)KP * L.ld * sizeof(double);
+    // bound flipping ratio test only where a variable has two finite, non-artificial bounds
+    bool bfrt = h->has_boxed;
+    if (!bfrt && L.vcnt > 0)
+        for (size_t k = 0; k < (size_t)B * L.vcnt && !bfrt; k++) bfrt = std::isfinite(vlo[k]) && std::isfinite(vup[k]) && vlo[k] < vup[k];
+    int cap2 = 2;
+    while (cap2 < L.N) cap2 <<= 1;
+    const size_t sel_lds = (size_t)cap2 * (sizeof(double) + sizeof(int)) + (size_t)L.N;
+    if (bfrt && sel_lds > h->select_lds_max) {
+        if (sel_lds <= 144 * 1024 && hipFuncSetAttribute((const void *)k_select<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds) == hipSuccess) h->select_lds_max = sel_lds;
+        else bfrt = false;       // rows too long for the in-LDS sort: plain ratio test
+    }
+    if (getenv("BSLV_NO_BFRT")) bfrt = false;
+    L.trace = getenv("BSLV_LP_TRACE") ? atoi(getenv("BSLV_LP_TRACE")) : -1;
     // One ROUND = KP lock-step selections on vectors, then one pass over the tableaux of the LPs that have something
     // pending (k_flush).  The status vector is read back every 1, 2, 4, ... rounds.
     int it = 0, chunk = 1, running = B;
@@ -781,7 +882,10 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     h->last_update_ms = 0;
     while (running > 0 && it < L.maxit + 8) {
         for (int c = 0; c < chunk; c++, it++) {
-            for (int lev = 0; lev < KP; lev++) hipLaunchKernelGGL(k_select, dim3(running), dim3(NT), 0, s, L, bv, h->active_d, running);
+            for (int lev = 0; lev < KP; lev++) {
+                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(NT), sel_lds, s, L, bv, h->active_d, running, cap2);
+                else hipLaunchKernelGGL(k_select<false>, dim3(running), dim3(NT), 0, s, L, bv, h->active_d, running, 0);
+            }
             hipLaunchKernelGGL(k_list_pending, dim3((running + 255) / 256), dim3(256), 0, s, bv, h->active_d, running, it);
             if (h->profile) {
                 if (nev == h->evpool.size()) {
