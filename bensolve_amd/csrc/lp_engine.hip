@@ -34,6 +34,9 @@ void set_error(const char *fmt, ...)
 constexpr int NS_L = 0, NS_U = 1, NS_F = 2, NS_S = 3;
 constexpr int ST_RUNNING = -1;
 constexpr int MODE_NONE = 0, MODE_PIVOT = 1, MODE_REFRESH = 2;
+constexpr int PF_PERT = 1, PF_PRIMAL = 2, PF_PERT_PENDING = 4, PF_USES_SHIFT = 8;   // BatchView::pflags
+constexpr int STALL_LIMIT = 3;         // consecutive degenerate pivots (dual step <= 1e-11) after which the costs are perturbed
+constexpr int PERT_MAX_USES = 3;       // perturbations per solve
 constexpr int KP = 6;                  // pivots selected between two passes over the tableau (delayed update; 4: 3.4 ms, 6: 3.0, 8: 3.1 ms per S-mid batch)
 constexpr int REFRESH_AFTER = 32;      // pivots of one solve after which optimality is only declared on a recomputed beta
 constexpr double TOL_BND = 1e-9, TOL_DJ = 1e-9, TOL_PIV = 1e-9;
@@ -44,7 +47,7 @@ constexpr int NT = 256;       // threads per workgroup
 struct PivDesc { int r, q; double p, pbeta, enter_val; };
 
 struct LpView {
-    int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit, bland_after, trace;
+    int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit, bland_after, trace, stall_limit;
     size_t slotT;
     double *T, *beta, *xN;
     int *bh, *nh, *nstat, *pos;
@@ -63,6 +66,9 @@ struct BatchView {
     double *prow;               // [B][KP][ld]   pivot rows as they were when chosen
     double *pcol;               // [B][KP][Mp1p] multipliers f_i = (entering column)_i * p of every row i (0 for the pivot row)
     double *dcur;               // [B][ld]       reduced-cost row of the LP, up to date
+    // Extended selection (k_select<true>): cost perturbation against dual degenerate stalling, primal clean-up afterwards
+    double *dper;               // [B][ld]       perturbed reduced costs (the ratio tests use them while PF_PERT is set)
+    int *pflags, *stall;        // PF_* bits; consecutive degenerate pivots
     int *work, *nwork;      // LPs whose tableau k_flush passes over in a round (k_list_pending), their number per round
 };
 
@@ -135,6 +141,8 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
         Bv.mode[b] = MODE_NONE;
         Bv.verified[b] = 1 | (bigm ? 2 : 0);   // k_init recomputes beta from scratch
         Bv.npend[b] = 0;
+        Bv.pflags[b] = 0;
+        Bv.stall[b] = 0;
         Bv.flushed[b] = src == dst;            // (in place: the slot already holds the tableau)
     }
 }
@@ -227,11 +235,24 @@ __device__ __forceinline__ double virt_entry(double v, int i, int j, int np, con
     return v;
 }
 
-// BFRT = bound flipping ("long step") ratio test, compiled in when the LP has boxed variables: the dual step passes the
-// breakpoints of boxed candidates -- they switch to their other bound instead of entering the basis -- for as long as the
-// leaving row stays infeasible.  Without it every boxed column with a zero reduced cost costs one degenerate pivot
-// (hypercube rows of S-degenerate: hundreds of thousands).  cap2 = capacity of the candidate arrays in dynamic LDS.
-template <bool BFRT>
+// EXT = the extended selection, compiled in when the LP has boxed variables (two finite, non-artificial bounds):
+//  * bound flipping ("long step") ratio test: the dual step passes the breakpoints of boxed candidates -- they switch to
+//    their other bound instead of entering the basis -- for as long as the leaving row stays infeasible.  Without it every
+//    boxed column with a zero reduced cost costs one degenerate pivot (hypercube rows of S-degenerate: hundreds of thousands);
+//  * cost perturbation after STALL_LIMIT consecutive degenerate pivots (the ratio tests then use dper, every nonbasic reduced
+//    cost moved 5e-7..1e-6 away from zero on its feasible side; the true reduced costs dcur are carried along);
+//  * when the perturbed problem is solved the perturbation is taken away: boxed columns whose true reduced cost has the wrong
+//    sign switch bound (dual simplex goes on), any other wrong sign is repaired by PRIMAL simplex pivots from the primal
+//    feasible basis at hand (Dantzig pricing, Harris ratio test on the entering column) -- oracle/lp_dense.c does the same
+//    with its primal_simplex().
+// cap2 = capacity of the candidate arrays in dynamic LDS.
+__device__ __forceinline__ double hash01(int k)
+{
+    unsigned x = (unsigned)k * 2654435761u;
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13;
+    return (double)(x >> 8) * (1.0 / 16777216.0);
+}
+template <bool EXT>
 __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact, int cap2)
 {
     __shared__ double sv[NT / WAVE];
@@ -260,11 +281,122 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     double *prow0 = Bv.prow + (size_t)b * KP * ld;
     double *pcol0 = Bv.pcol + (size_t)b * KP * L.Mp1p;
     double *drow = Bv.dcur + (size_t)b * ld;
-
-    // Phase A: leaving row = largest bound violation; id = 2*i + (below ? 1 : 0)
+    double *dwork = drow;                      // the reduced costs the dual ratio test works with
+    double *row = prow0 + (size_t)np * ld;     // the pivot row as it is after the pending pivots, where k_flush will read it
+    double *pc = pcol0 + (size_t)np * L.Mp1p;  // the multipliers of the rows (primal selection: first the entering column itself)
+    int pf = 0;
+    if constexpr (EXT) {
+        pf = Bv.pflags[b];
+        double *dp = Bv.dper + (size_t)b * ld;
+        if (pf & PF_PERT_PENDING) {
+            for (int j = tid; j < ld; j += NT) {
+                double v = j < N ? drow[j] : 0.0;
+                if (j < N) {
+                    const int st = nstat[j];
+                    const double eps = 5e-7 * (1.0 + hash01(nh[j]));
+                    if (st == NS_L) v = fmax(v, 0.0) + eps;
+                    else if (st == NS_U) v = fmin(v, 0.0) - eps;
+                }
+                dp[j] = v;
+            }
+            __syncthreads();
+            pf = (pf & ~PF_PERT_PENDING) | PF_PERT;
+            if (tid == 0) Bv.pflags[b] = pf;
+        }
+        if (pf & PF_PERT) dwork = dp;
+    }
     // anti-cycling: after `bland_after` pivots (a healthy solve needs far fewer) switch to Bland's rule --
     // smallest variable id among the infeasible rows, exact minimum ratio with smallest id among ties
-    const bool bland = Bv.iters[b] >= L.bland_after;
+    const bool bland = Bv.iters[b] >= L.bland_after && !(pf & PF_PERT);     // (perturbed costs break the ties themselves)
+    int r = -1, q = -1, nflip = 0;
+    bool below = false, have_col = false;
+
+    if (EXT && (pf & PF_PRIMAL)) {
+        // ---- primal simplex step on the true reduced costs (clean-up after a perturbation) ----
+        ValIdx ent{0.0, -1};
+        for (int j = tid; j < N; j += NT) {
+            const int st = nstat[j];
+            if (st == NS_S) continue;
+            const double v = drow[j];
+            double sc = 0.0;
+            if (st == NS_L) { if (v < -TOL_DJ) sc = -v; }
+            else if (st == NS_U) { if (v > TOL_DJ) sc = v; }
+            else if (fabs(v) > TOL_DJ) sc = fabs(v);
+            if (sc > 0.0) ent = better_max(ent, ValIdx{bland ? (double)(L.M + L.N - nh[j]) : sc, j});
+        }
+        ent = block_argmax(ent, sv, si);
+        if (ent.i < 0) {
+            // dual feasible: the dual selection takes over again (it concludes, or repairs what rounding left infeasible)
+            if (tid == 0) Bv.pflags[b] = pf & ~PF_PRIMAL;
+            return;
+        }
+        if (Bv.iters[b] >= L.maxit) {
+            if (tid == 0) { Bv.status[b] = BSLV_LP_UNDEFINED; Bv.mode[b] = MODE_NONE; }
+            return;
+        }
+        q = ent.i;
+        const int stq = nstat[q], kq = nh[q];
+        const double dq = drow[q];
+        const double dir = (stq == NS_U || (stq == NS_F && dq > 0.0)) ? -1.0 : 1.0;
+        for (int i = tid; i < M; i += NT) pc[i] = virt_entry(T0[(size_t)i * ld + q], i, q, np, pd, prow0, pcol0, ld, L.Mp1p);
+        __syncthreads();
+        double cmax = 0.0;
+        for (int i = tid; i < M; i += NT) cmax = fmax(cmax, fabs(pc[i]));
+        cmax = block_max(cmax, sv);
+        const double ptol = TOL_PIV * (1.0 + cmax);
+        const double gap = UP(L, Bv, b, kq) - LO(L, Bv, b, kq);     // inf unless both bounds are finite
+        double tmax = gap;
+        for (int i = tid; i < M; i += NT) {
+            const double a = pc[i] * dir;
+            if (fabs(a) < ptol) continue;
+            const int k = bh[i];
+            const double bt = beta[i];
+            if (a > 0) { const double up = UP(L, Bv, b, k); if (!isinf(up)) tmax = fmin(tmax, fmax(up + (bland ? 0.0 : btol(up)) - bt, 0.0) / a); }
+            else { const double lo = LO(L, Bv, b, k); if (!isinf(lo)) tmax = fmin(tmax, fmax(bt - lo + (bland ? 0.0 : btol(lo)), 0.0) / -a); }
+        }
+        tmax = block_min(tmax, sv);
+        if (isinf(tmax)) {
+            if (tid == 0) { Bv.status[b] = BSLV_LP_UNBOUNDED; Bv.mode[b] = MODE_NONE; }
+            return;
+        }
+        ValIdx lv{0.0, -1};
+        for (int i = tid; i < M; i += NT) {
+            const double a = pc[i] * dir;
+            if (fabs(a) < ptol) continue;
+            const int k = bh[i];
+            const double bt = beta[i];
+            if (a > 0) { const double up = UP(L, Bv, b, k); if (!isinf(up) && (up - bt) / a <= tmax) lv = better_max(lv, ValIdx{bland ? (double)(L.M + L.N - k) : a, 2 * i + 1}); }
+            else { const double lo = LO(L, Bv, b, k); if (!isinf(lo) && (bt - lo) / -a <= tmax) lv = better_max(lv, ValIdx{bland ? (double)(L.M + L.N - k) : -a, 2 * i}); }
+        }
+        lv = block_argmax(lv, sv, si);
+        double tstep = INFINITY;
+        if (lv.i >= 0) {
+            const int i = lv.i >> 1, k = bh[i];
+            const double a = pc[i] * dir;
+            tstep = fmax(((lv.i & 1) ? UP(L, Bv, b, k) - beta[i] : beta[i] - LO(L, Bv, b, k)) / fabs(a), 0.0);
+        }
+        if (lv.i < 0 || gap <= tstep) {
+            // the entering variable reaches its own other bound first: no pivot
+            __syncthreads();
+            for (int i = tid; i < M; i += NT) beta[i] = fma(pc[i], dir * gap, beta[i]);
+            if (tid == 0) {
+                beta[M] = fma(dq, dir * gap, beta[M]);
+                if (stq == NS_L) { nstat[q] = NS_U; xN[q] = UP(L, Bv, b, kq); } else { nstat[q] = NS_L; xN[q] = LO(L, Bv, b, kq); }
+                if (L.trace == b) printf("lp %d it %d primal: column %d (var %d) d %.3e switches bound\n", b, Bv.iters[b], q, kq, dq);
+                Bv.verified[b] &= 2;
+                Bv.iters[b] += 1;
+            }
+            return;
+        }
+        r = lv.i >> 1;
+        below = !(lv.i & 1);                   // the leaving variable goes to its lower bound
+        for (int j = tid; j < ld; j += NT)
+            row[j] = j < N ? virt_entry(T0[(size_t)r * ld + j], r, j, np, pd, prow0, pcol0, ld, L.Mp1p) : 0.0;
+        __syncthreads();
+        have_col = true;
+    } else {
+    // ---- dual simplex step ----
+    // Phase A: leaving row = largest bound violation; id = 2*i + (below ? 1 : 0)
     ValIdx best{0.0, -1};
     for (int i = tid; i < M; i += NT) {
         int k = bh[i];
@@ -274,6 +406,37 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     }
     best = block_argmax(best, sv, si);
     if (best.i < 0) {
+        if (EXT && (pf & PF_PERT)) {
+            // the perturbed problem is solved: take the perturbation away and look at the true reduced costs
+            int wrong1 = 0, wrongb = 0;
+            for (int j = tid; j < N; j += NT) {
+                const int st = nstat[j];
+                const double v = drow[j];
+                if ((st == NS_L && v < -TOL_DJ) || (st == NS_U && v > TOL_DJ) || (st == NS_F && fabs(v) > TOL_DJ)) {
+                    const int k = nh[j];
+                    if (st != NS_F && !isinf(LO(L, Bv, b, k)) && !isinf(UP(L, Bv, b, k)) && !L.art[k]) wrongb = 1; else wrong1 = 1;
+                }
+            }
+            wrong1 = __syncthreads_or(wrong1);
+            wrongb = __syncthreads_or(wrongb);
+            pf &= ~PF_PERT;
+            if (wrong1) {
+                if (tid == 0) { Bv.pflags[b] = pf | PF_PRIMAL; if (L.trace == b) printf("lp %d it %d perturbation off -> primal clean-up\n", b, Bv.iters[b]); }
+                return;
+            }
+            if (tid == 0) Bv.pflags[b] = pf;
+            if (wrongb) {
+                for (int j = tid; j < N; j += NT) {
+                    const int st = nstat[j], k = nh[j];
+                    const double v = drow[j];
+                    if (st == NS_L && v < -TOL_DJ) { nstat[j] = NS_U; xN[j] = UP(L, Bv, b, k); }
+                    else if (st == NS_U && v > TOL_DJ) { nstat[j] = NS_L; xN[j] = LO(L, Bv, b, k); }
+                }
+                if (tid == 0) { Bv.mode[b] = MODE_REFRESH; Bv.verified[b] &= 2; if (L.trace == b) printf("lp %d it %d perturbation off -> bound switches\n", b, Bv.iters[b]); }
+                return;
+            }
+            dwork = drow;
+        }
         // recompute beta from scratch before concluding -- unless this solve made only a few pivots since k_init computed
         // it from scratch: the rank-1 updates of beta then carry ~1e-15 of error against tolerances of 1e-9, and the
         // refresh is a full read of the tableau (4 MB per LP on S-mid)
@@ -297,11 +460,9 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         if (tid == 0) { Bv.status[b] = BSLV_LP_UNDEFINED; Bv.mode[b] = MODE_NONE; }
         return;
     }
-    const int r = best.i >> 1;
-    const bool below = best.i & 1;
+    r = best.i >> 1;
+    below = best.i & 1;
     const double sgn = below ? 1.0 : -1.0;
-    // the pivot row as it is after the pending pivots, written where k_flush will read it
-    double *row = prow0 + (size_t)np * ld;
     for (int j = tid; j < ld; j += NT)
         row[j] = j < N ? virt_entry(T0[(size_t)r * ld + j], r, j, np, pd, prow0, pcol0, ld, L.Mp1p) : 0.0;
     __syncthreads();
@@ -311,8 +472,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     for (int j = tid; j < N; j += NT) rmax = fmax(rmax, fabs(row[j]));
     rmax = block_max(rmax, sv);
     const double ptol = TOL_PIV * (1.0 + rmax);
-    int nflip = 0;
-    if constexpr (BFRT) {
+    if constexpr (EXT) {
         // candidates with their breakpoints; anything to flip at all?
         if (tid == 0) { s_cnt = 0; s_nboxed = 0; s_stop = 0; }
         for (int j = tid; j < N; j += NT) sflag[j] = 0;
@@ -324,7 +484,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
             if (fabs(a) < ptol) continue;
             if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F))) {
                 const int at = atomicAdd(&s_cnt, 1);
-                skey[at] = fabs(drow[j]) / fabs(a);
+                skey[at] = fabs(dwork[j]) / fabs(a);
                 sidx[at] = j;
                 const int k = nh[j];
                 const double lo = LO(L, Bv, b, k), up = UP(L, Bv, b, k);
@@ -377,11 +537,11 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     for (int j = tid; j < N; j += NT) {
         int st = nstat[j];
         if (st == NS_S) continue;
-        if (BFRT && sflag[j]) continue;
+        if (EXT && sflag[j]) continue;
         double a = sgn * row[j];
         if (fabs(a) < ptol) continue;
         if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
-            th = fmin(th, (fabs(drow[j]) + (bland ? 0.0 : TOL_DJ)) / fabs(a));
+            th = fmin(th, (fabs(dwork[j]) + (bland ? 0.0 : TOL_DJ)) / fabs(a));
     }
     th = block_min(th, sv);
     if (isinf(th)) {                      // no entering candidate: primal infeasible ...
@@ -397,15 +557,15 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     for (int j = tid; j < N; j += NT) {
         int st = nstat[j];
         if (st == NS_S) continue;
-        if (BFRT && sflag[j]) continue;
+        if (EXT && sflag[j]) continue;
         double a = sgn * row[j];
         if (fabs(a) < ptol) continue;
         if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
-            if (fabs(drow[j]) / fabs(a) <= th) piv = better_max(piv, ValIdx{bland ? (double)(L.M + L.N - nh[j]) : fabs(a), j});
+            if (fabs(dwork[j]) / fabs(a) <= th) piv = better_max(piv, ValIdx{bland ? (double)(L.M + L.N - nh[j]) : fabs(a), j});
     }
     piv = block_argmax(piv, sv, si);
-    const int q = piv.i;
-    if constexpr (BFRT) {
+    q = piv.i;
+    if constexpr (EXT) {
         // the switches: other bound, other status.  beta no longer matches xN: this pivot is applied at once and beta
         // recomputed from the new tableau (MODE_REFRESH below), before the LP selects again
         for (int k = tid; k < nflip; k += NT) {
@@ -413,6 +573,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
             if (nstat[j] == NS_L) { nstat[j] = NS_U; xN[j] = UP(L, Bv, b, kv); }
             else { nstat[j] = NS_L; xN[j] = LO(L, Bv, b, kv); }
         }
+    }
     }
     // Phase C: the descriptor, the basis heads
     if (tid == 0) {
@@ -432,8 +593,19 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         if (lo == up) { nstat[q] = NS_S; xN[q] = lo; }
         else if (below) { nstat[q] = NS_L; xN[q] = lo; }
         else { nstat[q] = NS_U; xN[q] = up; }
-        if (L.trace == b && (Bv.iters[b] < 300 || Bv.iters[b] % 997 == 0)) printf("lp %d it %d r %d (var %d, %s by %.3e) q %d (var %d) alpha %.3e d %.3e step %.3e flips %d obj %.12g%s\n", b, Bv.iters[b], r, kb, below ? "below" : "above",
-                                 below ? lo - br : br - up, q, kn, trq, drow[q], fabs(drow[q] / trq), nflip, beta[M], bland ? " bland" : "");
+        if (L.trace == b && (Bv.iters[b] < 300 || Bv.iters[b] % 997 == 0)) printf("lp %d it %d%s r %d (var %d, %s by %.3e) q %d (var %d) alpha %.3e d %.3e step %.3e flips %d obj %.12g%s%s\n", b, Bv.iters[b], have_col ? " primal" : "", r, kb, below ? "below" : "above",
+                                 below ? lo - br : br - up, q, kn, trq, dwork[q], fabs(dwork[q] / trq), nflip, beta[M], bland ? " bland" : "", (pf & PF_PERT) ? " perturbed" : "");
+        if constexpr (EXT) {
+            if (!have_col) {
+                // dual degenerate stalling: perturb the costs from the next selection on
+                int stl = fabs(dwork[q] / trq) <= 1e-11 ? Bv.stall[b] + 1 : 0;
+                if (stl >= L.stall_limit && !(pf & PF_PERT) && (pf >> PF_USES_SHIFT) < PERT_MAX_USES) {
+                    Bv.pflags[b] = (pf | PF_PERT_PENDING) + (1 << PF_USES_SHIFT);
+                    stl = 0;
+                }
+                Bv.stall[b] = stl;
+            }
+        }
         Bv.mode[b] = nflip > 0 ? MODE_REFRESH : MODE_PIVOT;
         Bv.verified[b] &= 2;
         Bv.iters[b] += 1;
@@ -441,10 +613,9 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     __syncthreads();
     const PivDesc d = s_d;
     // Phase D: the entering column as it is after the pending pivots -> multipliers of all rows, beta; the reduced-cost row
-    double *pc = pcol0 + (size_t)np * L.Mp1p;
     for (int i = tid; i <= M; i += NT) {
         if (i == r) { pc[i] = 0.0; beta[i] = d.enter_val; continue; }
-        const double f = (i == M ? drow[q] : virt_entry(T0[(size_t)i * ld + q], i, q, np, pd, prow0, pcol0, ld, L.Mp1p)) * d.p;
+        const double f = (i == M ? drow[q] : (have_col ? pc[i] : virt_entry(T0[(size_t)i * ld + q], i, q, np, pd, prow0, pcol0, ld, L.Mp1p))) * d.p;
         pc[i] = f;
         beta[i] = fma(-f, d.pbeta, beta[i]);
     }
@@ -452,6 +623,14 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     {
         const double fM = pc[M];
         for (int j = tid; j < N; j += NT) drow[j] = j == q ? fM : fma(-fM, row[j], drow[j]);
+        if constexpr (EXT) {
+            if (pf & PF_PERT) {
+                double *dp = Bv.dper + (size_t)b * ld;
+                const double fP = dp[q] * d.p;
+                __syncthreads();
+                for (int j = tid; j < N; j += NT) dp[j] = j == q ? fP : fma(-fP, row[j], dp[j]);
+            }
+        }
     }
     if (tid == 0) Bv.npend[b] = np + 1;
 }
@@ -608,6 +787,7 @@ struct bslv_lpq {
     int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
     int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
+    double *dper_d = nullptr; int *pflags_d = nullptr, *stall_d = nullptr;
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
     size_t select_lds_max = 64 * 1024; // dynamic LDS of k_select<true> (candidate sort of the bound flipping ratio test)
     bool has_boxed = false;            // some variable outside the per-LP range has two finite, non-artificial bounds
@@ -632,7 +812,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     int cap = std::max(B, h->Bcap * 2);
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d); fr(h->work_d);
-    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
     h->Bcap = 0;
@@ -650,6 +830,9 @@ static int ensure_batch(bslv_lpq *h, int B)
     HIP_TRY(hipMalloc(&h->desc_d, (size_t)cap * KP * sizeof(PivDesc)));
     HIP_TRY(hipMalloc(&h->pcol_d, (size_t)cap * KP * h->L.Mp1p * sizeof(double)));
     HIP_TRY(hipMalloc(&h->dcur_d, (size_t)cap * h->L.ld * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->dper_d, (size_t)cap * h->L.ld * sizeof(double)));
+    HIP_TRY(hipMalloc(&h->pflags_d, cap * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->stall_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->npend_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->flushed_d, cap * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->status_h, cap * sizeof(int)));
@@ -666,6 +849,7 @@ static BatchView bview(bslv_lpq *h)
     v.status = h->status_d; v.iters = h->iters_d; v.mode = h->mode_d; v.verified = h->ver_d;
     v.desc = h->desc_d; v.prow = h->prow_d; v.pcol = h->pcol_d; v.dcur = h->dcur_d; v.npend = h->npend_d; v.flushed = h->flushed_d;
     v.work = h->work_d; v.nwork = h->nwork_d;
+    v.dper = h->dper_d; v.pflags = h->pflags_d; v.stall = h->stall_d;
     return v;
 }
 
@@ -782,7 +966,7 @@ void bslv_lpq_destroy(bslv_lpq *h)
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
-    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
     for (auto &e : h->evpool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -873,6 +1057,7 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     }
     if (getenv("BSLV_NO_BFRT")) bfrt = false;
     L.trace = getenv("BSLV_LP_TRACE") ? atoi(getenv("BSLV_LP_TRACE")) : -1;
+    L.stall_limit = getenv("BSLV_STALL_LIMIT") ? atoi(getenv("BSLV_STALL_LIMIT")) : STALL_LIMIT;
     // One ROUND = KP lock-step selections on vectors, then one pass over the tableaux of the LPs that have something
     // pending (k_flush).  The status vector is read back every 1, 2, 4, ... rounds.
     int it = 0, chunk = 1, running = B;

@@ -18,9 +18,9 @@ def run(trace_at=None):
         rec, piv, ls = eng.solve_local(nl)
         os.environ.pop("BSLV_LP_TRACE", None)
         if trace_at and trace_at[0] == k: return None
-        bad = [i for i in range(nl) if int(rec[i, 1]) != 0]
+        bad = [i for i in range(nl) if int(rec[i, 1]) != 4]
         print("step", k, "lps", nl, "pivots", piv, "lockstep", ls, "status", [int(x) for x in rec[:, 1]], flush=True)
-        if bad or ls > 300:
+        if bad:
             its = eng.lp_iters() if hasattr(eng, "lp_iters") else None
             return (k, bad[0] if bad else 0)
         eng.apply(rec)
