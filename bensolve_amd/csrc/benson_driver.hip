@@ -27,7 +27,8 @@ using clk = std::chrono::steady_clock;
 static double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
 
 struct bslv_benson {
-    int m = 0, n = 0, q = 0, r = 0, M = 0, N = 0;
+    int m = 0, n = 0, q = 0, r = 0, M = 0, N = 0;     // m: rows of A left after the presolve
+    int rows_folded = 0;                              // singleton rows of A turned into column bounds
     double eps = 1e-7;
     std::vector<double> R, c;           // q x r (generators as columns), q
     bslv_lpq *lp = nullptr;
@@ -92,6 +93,30 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
         return BSLV_E_ARG;
     }
     bslv_benson *h = new bslv_benson();
+    // Presolve: a row of A with a single non-zero is a bound on that column (the hypercube rows of S-degenerate, SURVEY 8d;
+    // ex/example10.m:21-24 states its box the same way).  It is folded into the column's bounds and dropped from the LP: the
+    // LP loses a row, and the column becomes boxed, which is what the bound flipping ratio test of the LP engine works on.
+    // Only y* (duals of the q objective rows) and y leave the LP layer in phase 2, so no dual of a folded row is ever read.
+    std::vector<double> clo(n), cup(n);
+    for (int j = 0; j < n; j++) bounds_of(ctype[j], clb ? clb[j] : 0, cub ? cub[j] : 0, &clo[j], &cup[j]);
+    std::vector<int> keep;
+    keep.reserve(m);
+    for (int i = 0; i < m; i++) {
+        int nz = 0, jj = -1;
+        for (int j = 0; j < n && nz < 2; j++) if (A[(size_t)i * n + j] != 0.0) { nz++; jj = j; }
+        double lo_i, up_i;
+        bounds_of(rtype[i], rlb ? rlb[i] : 0, rub ? rub[i] : 0, &lo_i, &up_i);
+        if (nz == 1 && !getenv("BSLV_NO_PRESOLVE")) {
+            const double a = A[(size_t)i * n + jj];
+            double lo = a > 0 ? lo_i / a : up_i / a, up = a > 0 ? up_i / a : lo_i / a;
+            lo = std::max(lo, clo[jj]); up = std::min(up, cup[jj]);
+            if (lo <= up) { clo[jj] = lo; cup[jj] = up; continue; }        // (an empty box stays a row: the LP reports it)
+        }
+        keep.push_back(i);
+    }
+    h->rows_folded = m - (int)keep.size();
+    if (keep.empty()) { keep.push_back(0); h->rows_folded = m - 1; }      // (the LP layer wants at least one row of A)
+    m = (int)keep.size();
     h->m = m; h->n = n; h->q = q; h->r = r; h->eps = eps;
     h->R.assign(R, R + (size_t)q * r);
     h->c.assign(c, c + q);
@@ -100,7 +125,7 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
     const int M = m + q + r + 1, N = n + q + 1;
     h->M = M; h->N = N;
     std::vector<double> L((size_t)M * N, 0.0), lo(M + N), up(M + N), cost(N + 1, 0.0);
-    for (int i = 0; i < m; i++) memcpy(&L[(size_t)i * N], A + (size_t)i * n, n * sizeof(double));
+    for (int i = 0; i < m; i++) memcpy(&L[(size_t)i * N], A + (size_t)keep[i] * n, n * sizeof(double));
     for (int k = 0; k < q; k++) {
         for (int j = 0; j < n; j++) L[(size_t)(m + k) * N + j] = -P[(size_t)k * n + j];
         L[(size_t)(m + k) * N + n + k] = 1.0;
@@ -109,11 +134,11 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
         for (int k = 0; k < q; k++) L[(size_t)(m + q + i) * N + n + k] = R[(size_t)k * r + i];
         L[(size_t)(m + q + i) * N + n + q] = -1.0;
     }
-    for (int i = 0; i < m; i++) bounds_of(rtype[i], rlb ? rlb[i] : 0, rub ? rub[i] : 0, &lo[i], &up[i]);
+    for (int i = 0; i < m; i++) bounds_of(rtype[keep[i]], rlb ? rlb[keep[i]] : 0, rub ? rub[keep[i]] : 0, &lo[i], &up[i]);
     for (int k = 0; k < q; k++) { lo[m + k] = 0; up[m + k] = 0; }
     for (int i = 0; i < r; i++) { lo[m + q + i] = -INFINITY; up[m + q + i] = 0; }
     lo[m + q + r] = -INFINITY; up[m + q + r] = INFINITY;
-    for (int j = 0; j < n; j++) bounds_of(ctype[j], clb ? clb[j] : 0, cub ? cub[j] : 0, &lo[M + j], &up[M + j]);
+    for (int j = 0; j < n; j++) { lo[M + j] = clo[j]; up[M + j] = cup[j]; }
     for (int j = n; j < N; j++) { lo[M + j] = -INFINITY; up[M + j] = INFINITY; }
     cost[N] = 1.0;
     int rc = bslv_lpq_create(&h->lp, M, N, L.data(), lo.data(), up.data(), cost.data(), m + q, r, pool_slots);

@@ -6,7 +6,7 @@ from bensolve_amd import synth
 from bensolve_amd.benson import BensonEngine
 from degen_fold import fold
 m, n, q, steps, batch = [int(x) for x in sys.argv[1:6]]
-prob = fold(synth.degenerate_vlp(m, n, q, 3))
+prob = synth.degenerate_vlp(m, n, q, 3)      # (the driver's presolve folds the hypercube rows)
 t0 = time.time()
 eng = BensonEngine(prob, eps=1e-7, pool_slots=max(40, 2 * batch + 8))
 print("start", eng.start(), eng.totals(), "%.1fs" % (time.time() - t0), flush=True)
@@ -17,5 +17,6 @@ for k in range(steps):
     bad = [int(x) for x in rec[:, 1] if int(x) != 4]
     print("step", k, "lps", nl, "pivots", piv, "lockstep", ls, "not optimal", bad, "%.1fs" % (time.time() - t0), flush=True)
     if bad: break
+    t1 = time.time()
     st = eng.apply(rec)
-    print("     cuts", st["cuts"], flush=True)
+    print("     cuts", st["cuts"], "apply %.2fs" % (time.time() - t1), "paths", eng.poly_call("path_stats"), flush=True)
