@@ -49,6 +49,7 @@ struct PivDesc { int r, q; double p, pbeta, enter_val; };
 struct LpView {
     int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit, bland_after, trace, stall_limit;
     size_t slotT;
+    double pert_scale;          // multiplies the cost perturbation (1; tests raise it to force the clean-up paths)
     double *T, *beta, *xN;
     int *bh, *nh, *nstat, *pos;
     const double *lb, *ub;
@@ -69,6 +70,7 @@ struct BatchView {
     // Extended selection (k_select<true>): cost perturbation against dual degenerate stalling, primal clean-up afterwards
     double *dper;               // [B][ld]       perturbed reduced costs (the ratio tests use them while PF_PERT is set)
     int *pflags, *stall;        // PF_* bits; consecutive degenerate pivots
+    int *xstat;                 // [4] of the batch: iterations with bound switches, perturbations, primal steps, removals that left wrong signs
     int *work, *nwork;      // LPs whose tableau k_flush passes over in a round (k_list_pending), their number per round
 };
 
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
                 double v = j < N ? drow[j] : 0.0;
                 if (j < N) {
                     const int st = nstat[j];
-                    const double eps = 5e-7 * (1.0 + hash01(nh[j]));
+                    const double eps = 5e-7 * L.pert_scale * (1.0 + hash01(nh[j]));
                     if (st == NS_L) v = fmax(v, 0.0) + eps;
                     else if (st == NS_U) v = fmin(v, 0.0) - eps;
                 }
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
             }
             __syncthreads();
             pf = (pf & ~PF_PERT_PENDING) | PF_PERT;
-            if (tid == 0) Bv.pflags[b] = pf;
+            if (tid == 0) { Bv.pflags[b] = pf; atomicAdd(&Bv.xstat[1], 1); }
         }
         if (pf & PF_PERT) dwork = dp;
     }
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
                 if (L.trace == b) printf("lp %d it %d primal: column %d (var %d) d %.3e switches bound\n", b, Bv.iters[b], q, kq, dq);
                 Bv.verified[b] &= 2;
                 Bv.iters[b] += 1;
+                atomicAdd(&Bv.xstat[2], 1);
             }
             return;
         }
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
             wrong1 = __syncthreads_or(wrong1);
             wrongb = __syncthreads_or(wrongb);
             pf &= ~PF_PERT;
+            if (tid == 0 && (wrong1 || wrongb)) atomicAdd(&Bv.xstat[3], 1);
             if (wrong1) {
                 if (tid == 0) { Bv.pflags[b] = pf | PF_PRIMAL; if (L.trace == b) printf("lp %d it %d perturbation off -> primal clean-up\n", b, Bv.iters[b]); }
                 return;
@@ -596,6 +600,8 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         if (L.trace == b && (Bv.iters[b] < 300 || Bv.iters[b] % 997 == 0)) printf("lp %d it %d%s r %d (var %d, %s by %.3e) q %d (var %d) alpha %.3e d %.3e step %.3e flips %d obj %.12g%s%s\n", b, Bv.iters[b], have_col ? " primal" : "", r, kb, below ? "below" : "above",
                                  below ? lo - br : br - up, q, kn, trq, dwork[q], fabs(dwork[q] / trq), nflip, beta[M], bland ? " bland" : "", (pf & PF_PERT) ? " perturbed" : "");
         if constexpr (EXT) {
+            if (nflip > 0) atomicAdd(&Bv.xstat[0], 1);
+            if (have_col) atomicAdd(&Bv.xstat[2], 1);
             if (!have_col) {
                 // dual degenerate stalling: perturb the costs from the next selection on
                 int stl = fabs(dwork[q] / trq) <= 1e-11 ? Bv.stall[b] + 1 : 0;
@@ -787,7 +793,8 @@ struct bslv_lpq {
     int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
     int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
-    double *dper_d = nullptr; int *pflags_d = nullptr, *stall_d = nullptr;
+    double *dper_d = nullptr; int *pflags_d = nullptr, *stall_d = nullptr, *xstat_d = nullptr;
+    long last_ext[4] = {0, 0, 0, 0};
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
     size_t select_lds_max = 64 * 1024; // dynamic LDS of k_select<true> (candidate sort of the bound flipping ratio test)
     bool has_boxed = false;            // some variable outside the per-LP range has two finite, non-artificial bounds
@@ -833,6 +840,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     HIP_TRY(hipMalloc(&h->dper_d, (size_t)cap * h->L.ld * sizeof(double)));
     HIP_TRY(hipMalloc(&h->pflags_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->stall_d, cap * sizeof(int)));
+    if (!h->xstat_d) HIP_TRY(hipMalloc(&h->xstat_d, 4 * sizeof(int)));
     HIP_TRY(hipMalloc(&h->npend_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->flushed_d, cap * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->status_h, cap * sizeof(int)));
@@ -849,7 +857,7 @@ static BatchView bview(bslv_lpq *h)
     v.status = h->status_d; v.iters = h->iters_d; v.mode = h->mode_d; v.verified = h->ver_d;
     v.desc = h->desc_d; v.prow = h->prow_d; v.pcol = h->pcol_d; v.dcur = h->dcur_d; v.npend = h->npend_d; v.flushed = h->flushed_d;
     v.work = h->work_d; v.nwork = h->nwork_d;
-    v.dper = h->dper_d; v.pflags = h->pflags_d; v.stall = h->stall_d;
+    v.dper = h->dper_d; v.pflags = h->pflags_d; v.stall = h->stall_d; v.xstat = h->xstat_d;
     return v;
 }
 
@@ -966,7 +974,7 @@ void bslv_lpq_destroy(bslv_lpq *h)
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
-    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d); fr(h->xstat_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
     for (auto &e : h->evpool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1038,6 +1046,7 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
         if (need > h->nworkcap) { if (h->nwork_d) (void)hipFree(h->nwork_d); h->nwork_d = nullptr; HIP_TRY(hipMalloc(&h->nwork_d, need * sizeof(int))); h->nworkcap = need; }
         HIP_TRY(hipMemsetAsync(h->nwork_d, 0, need * sizeof(int), s));
     }
+    HIP_TRY(hipMemsetAsync(h->xstat_d, 0, 4 * sizeof(int), s));
     BatchView bv = bview(h);
     const int tiles = (L.Mp1 + TR - 1) / TR;
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(NT), 0, s, L, bv, B);
@@ -1048,6 +1057,7 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     bool bfrt = h->has_boxed;
     if (!bfrt && L.vcnt > 0)
         for (size_t k = 0; k < (size_t)B * L.vcnt && !bfrt; k++) bfrt = std::isfinite(vlo[k]) && std::isfinite(vup[k]) && vlo[k] < vup[k];
+    if (getenv("BSLV_LP_EXT")) bfrt = atoi(getenv("BSLV_LP_EXT")) != 0;      // test hook: force the extended selection on / off
     int cap2 = 2;
     while (cap2 < L.N) cap2 <<= 1;
     const size_t sel_lds = (size_t)cap2 * (sizeof(double) + sizeof(int)) + (size_t)L.N;
@@ -1055,9 +1065,9 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
         if (sel_lds <= 144 * 1024 && hipFuncSetAttribute((const void *)k_select<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds) == hipSuccess) h->select_lds_max = sel_lds;
         else bfrt = false;       // rows too long for the in-LDS sort: plain ratio test
     }
-    if (getenv("BSLV_NO_BFRT")) bfrt = false;
     L.trace = getenv("BSLV_LP_TRACE") ? atoi(getenv("BSLV_LP_TRACE")) : -1;
     L.stall_limit = getenv("BSLV_STALL_LIMIT") ? atoi(getenv("BSLV_STALL_LIMIT")) : STALL_LIMIT;
+    L.pert_scale = getenv("BSLV_PERT_SCALE") ? atof(getenv("BSLV_PERT_SCALE")) : 1.0;
     // One ROUND = KP lock-step selections on vectors, then one pass over the tableaux of the LPs that have something
     // pending (k_flush).  The status vector is read back every 1, 2, 4, ... rounds.
     int it = 0, chunk = 1, running = B;
@@ -1118,6 +1128,7 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
         if (iters) memcpy(iters, itv.data(), B * sizeof(int));
     }
     h->last_iters = it;
+    { int xs[4]; HIP_TRY(hipMemcpy(xs, h->xstat_d, sizeof xs, hipMemcpyDeviceToHost)); for (int k = 0; k < 4; k++) h->last_ext[k] = xs[k]; }
     if (h->profile) {
         double ms = 0;
         for (size_t e = 0; e < nev; e++) { float t = 0; (void)hipEventElapsedTime(&t, h->evpool[e].first, h->evpool[e].second); ms += t; }
@@ -1174,6 +1185,12 @@ int bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out)
 }
 
 long bslv_lpq_last_passes(const bslv_lpq *h) { return h ? h->last_passes : 0; }
+int bslv_lpq_last_ext_stats(const bslv_lpq *h, long out[4])
+{
+    if (!h || !out) return BSLV_E_ARG;
+    for (int k = 0; k < 4; k++) out[k] = h->last_ext[k];
+    return 0;
+}
 int bslv_lpq_last_stats(const bslv_lpq *h, int *lockstep_iters, long *pivots, double *update_ms, double *total_ms)
 {
     if (!h) return BSLV_E_ARG;

@@ -143,6 +143,10 @@ class LpEngine:
         ums = ctypes.c_double()
         tms = ctypes.c_double()
         check(self.lib.bslv_lpq_last_stats(self.h, ctypes.byref(it), ctypes.byref(piv), ctypes.byref(ums), ctypes.byref(tms)))
+        ext = (ctypes.c_long * 4)()
+        self.lib.bslv_lpq_last_ext_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.bslv_lpq_last_ext_stats(self.h, ext)
         self.lib.bslv_lpq_last_passes.restype = ctypes.c_long
         self.lib.bslv_lpq_last_passes.argtypes = [ctypes.c_void_p]
-        return dict(lockstep_iters=it.value, pivots=piv.value, update_ms=ums.value, total_ms=tms.value, passes=self.lib.bslv_lpq_last_passes(self.h))
+        return dict(lockstep_iters=it.value, pivots=piv.value, update_ms=ums.value, total_ms=tms.value, passes=self.lib.bslv_lpq_last_passes(self.h),
+                    flip_iterations=ext[0], perturbations=ext[1], primal_steps=ext[2], wrong_sign_removals=ext[3])

@@ -57,6 +57,38 @@ def degenerate_vlp(m, n, q, seed):
                 ctype=np.full(n, ord("f"), np.uint8), clb=np.zeros(n), cub=np.zeros(n))
 
 
+def fold_singleton_rows(prob):
+    """Rows of A with a single non-zero become bounds of that column (what the batched driver's presolve does,
+    bensolve_amd/csrc/benson_driver.hip bslv_benson_create): same VLP, smaller LP, boxed columns."""
+    A = prob["A"]
+    n = prob["n"]
+    lo_of = {ord("f"): lambda l, u: (-np.inf, np.inf), ord("l"): lambda l, u: (l, np.inf), ord("u"): lambda l, u: (-np.inf, u),
+             ord("d"): lambda l, u: (l, u), ord("s"): lambda l, u: (l, l)}
+    clo = np.empty(n); cup = np.empty(n)
+    for j in range(n):
+        clo[j], cup[j] = lo_of[int(prob["ctype"][j])](prob["clb"][j], prob["cub"][j])
+    keep = []
+    for i in range(prob["m"]):
+        nz = np.flatnonzero(A[i])
+        if len(nz) == 1:
+            j = int(nz[0]); a = A[i, j]
+            lo, up = lo_of[int(prob["rtype"][i])](prob["rlb"][i], prob["rub"][i])
+            lo, up = (lo / a, up / a) if a > 0 else (up / a, lo / a)
+            lo, up = max(lo, clo[j]), min(up, cup[j])
+            if lo <= up:
+                clo[j], cup[j] = lo, up
+                continue
+        keep.append(i)
+    ctype = np.empty(n, np.uint8)
+    for j in range(n):
+        fl, fu = np.isfinite(clo[j]), np.isfinite(cup[j])
+        ctype[j] = ord("s") if fl and fu and clo[j] == cup[j] else ord("d") if fl and fu else ord("l") if fl else ord("u") if fu else ord("f")
+    out = dict(prob)
+    out.update(m=len(keep), A=np.ascontiguousarray(A[keep]), rtype=prob["rtype"][keep].copy(), rlb=prob["rlb"][keep].copy(),
+               rub=prob["rub"][keep].copy(), ctype=ctype, clb=np.where(np.isfinite(clo), clo, 0.0), cub=np.where(np.isfinite(cup), cup, 0.0))
+    return out
+
+
 CONFIGS = {
     "S-small": lambda: covering_vlp(200, 100, 3, 1),
     "S-mid": lambda: covering_vlp(1000, 500, 5, 2),

@@ -129,3 +129,127 @@ def test_chains_of_warm_starts_through_unpivoted_slots(oracle):
     y = eng.primal(gen3, model.M + model.n, model.q)
     _check_identities(model, V, eng.obj(gen3), w, y)
     olp.close()
+
+
+@pytest.mark.parametrize("m,n,q,seed,B", [(60, 30, 3, 3, 40), (240, 120, 4, 5, 96)])
+def test_boxed_degenerate_batch_matches_oracle(oracle, m, n, q, seed, B):
+    """Hypercube LPs of the S-degenerate family (columns boxed after the singleton-row presolve, integer data: ties in every
+    ratio test).  Exercises the extended selection of the engine -- long-step ratio test, cost perturbation, clean-up --
+    whose work the stats report; objective values against the oracle's dual+primal simplex."""
+    import oracle_api
+    prob = synth.fold_singleton_rows(synth.degenerate_vlp(m, n, q, seed))
+    assert prob["m"] == m - n and np.all(prob["ctype"] == ord("d"))
+    model = P2Model(prob)
+    rng = np.random.default_rng(seed)
+    X = rng.random((B, n))
+    V = X @ prob["P"].T + rng.normal(scale=0.5, size=(B, q))
+    V[: B // 4] = np.round(V[: B // 4])              # lattice points: the most degenerate right-hand sides
+    ub = model.ub_for(V)
+    olp = oracle_api.OracleLP(model.L, model.lo, model.up, model.cost)
+    exp_obj = np.empty(B)
+    for b in range(B):
+        for j in range(model.r):
+            olp.set_bound(model.var_first + j, -np.inf, ub[b, j])
+        assert olp.solve(1) == 4
+        exp_obj[b] = olp.obj()
+    olp.close()
+    eng = LpEngine.from_model(model, pool_slots=B + 1)
+    eng.reset_slot(0)
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+    assert st[0] == 4, "cold start failed"
+    cold = eng.last_stats()
+    assert cold["flip_iterations"] > 0, cold          # the cold start moves boxed columns to their other bound in bulk
+    assert it[0] < 20 * (q + 2), (it, cold)           # ... instead of one degenerate pivot per column
+    src = np.zeros(B, np.int32)
+    dst = np.arange(1, B + 1, dtype=np.int32)
+    st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+    stats = eng.last_stats()
+    assert np.all(st == 4), (st, stats)
+    obj = eng.obj(dst)
+    np.testing.assert_allclose(obj, exp_obj, rtol=RTOL, atol=1e-9)
+    w = eng.dual(dst, model.w_first, q)
+    y = eng.primal(dst, model.y_first, q)
+    _check_identities(model, V, obj, w, y)
+    # primal feasibility of the box and of the cover rows at the reported optimum
+    x = eng.primal(dst, model.M, n)
+    assert np.all(x >= -1e-9) and np.all(x <= 1 + 1e-9)
+    assert np.all(x @ prob["A"].T >= 1 - 1e-8)
+    np.testing.assert_allclose(x @ prob["P"].T, y, rtol=0, atol=1e-8)
+    eng.close()
+
+
+def test_s_degenerate_full_size_lps_are_certified():
+    """BASELINE.json configs[4] at full size (m=4000, n=2000, q=10; 2021 x 2011 tableau after the presolve), too large for
+    the CPU oracle: every reported optimum is certified by size-independent bounds -- the returned x is feasible and attains
+    z (upper bound), and the returned weights w give the Lagrangian lower bound min_{x in box} w.(Px - v) in closed form;
+    where the two meet the LP is solved to optimality, and they must never cross."""
+    prob = synth.fold_singleton_rows(synth.CONFIGS["S-degenerate"]())
+    m, n, q = prob["m"], prob["n"], prob["q"]
+    assert (m, n, q) == (2000, 2000, 10)
+    model = P2Model(prob)
+    B = 24
+    rng = np.random.default_rng(4)
+    V = rng.random((B, n)) @ prob["P"].T + rng.normal(scale=2.0, size=(B, q))
+    V[:6] = np.round(V[:6])
+    ub = model.ub_for(V)
+    eng = LpEngine.from_model(model, pool_slots=B + 1)
+    eng.reset_slot(0)
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+    assert st[0] == 4 and it[0] < 500, (st, it, eng.last_stats())     # (without the long-step ratio test: > 3e5 pivots, no result)
+    src = np.zeros(B, np.int32)
+    dst = np.arange(1, B + 1, dtype=np.int32)
+    st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+    stats = eng.last_stats()
+    assert np.all(st == 4), (st, stats)
+    assert it.max() < 2000, (it, stats)
+    obj = eng.obj(dst)
+    w = eng.dual(dst, model.w_first, q)
+    y = eng.primal(dst, model.y_first, q)
+    x = eng.primal(dst, model.M, n)
+    eng.close()
+    _check_identities(model, V, obj, w, y)
+    assert np.all(x >= -1e-9) and np.all(x <= 1 + 1e-9) and np.all(x @ prob["A"].T >= 1 - 1e-7)
+    np.testing.assert_allclose(x @ prob["P"].T, y, rtol=0, atol=1e-7)
+    wp = w @ prob["P"]                                   # (B, n): cost of x under the weights
+    lower = np.minimum(wp, 0.0).sum(axis=1) - np.einsum("bk,bk->b", w, V)
+    assert np.all(lower <= obj + 1e-7), (lower - obj).max()
+    assert np.mean(np.abs(lower - obj) <= 1e-7) >= 0.9, np.abs(lower - obj)
+
+
+@pytest.mark.parametrize("scale", ["1e4", "1e6"])
+def test_forced_perturbation_and_primal_cleanup_reach_the_same_optimum(oracle, monkeypatch, scale):
+    """The clean-up after a cost perturbation, forced: extended selection on for an LP without boxed variables, costs
+    perturbed from the first pivot by 5e-3 .. 1 instead of 5e-7 .. 1e-6.  The perturbed optimum is then a different vertex,
+    removing the perturbation leaves reduced costs of the wrong sign on one-sided variables, and primal simplex steps have to
+    walk back to the true optimum: same objective values as the oracle, same LP identities."""
+    import oracle_api
+    m, n, q, seed, B = 200, 100, 3, 1, 200
+    prob = synth.covering_vlp(m, n, q, seed)
+    model = P2Model(prob)
+    rng = np.random.default_rng(seed)
+    V = _random_V(model, prob, rng, B)
+    ub = model.ub_for(V)
+    olp = oracle_api.OracleLP(model.L, model.lo, model.up, model.cost)
+    exp_obj = np.empty(B)
+    for b in range(B):
+        for j in range(model.r):
+            olp.set_bound(model.var_first + j, -np.inf, ub[b, j])
+        assert olp.solve(1) == 4
+        exp_obj[b] = olp.obj()
+    olp.close()
+    monkeypatch.setenv("BSLV_LP_EXT", "1")
+    monkeypatch.setenv("BSLV_STALL_LIMIT", "0")
+    monkeypatch.setenv("BSLV_PERT_SCALE", scale)
+    eng = LpEngine.from_model(model, pool_slots=B + 1)
+    eng.reset_slot(0)
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+    assert st[0] == 4
+    dst = np.arange(1, B + 1, dtype=np.int32)
+    st, it = eng.solve_batch(np.zeros(B, np.int32), dst, np.full((B, model.r), -np.inf), ub)
+    stats = eng.last_stats()
+    assert np.all(st == 4), (st, stats)
+    assert stats["perturbations"] > B // 2 and stats["wrong_sign_removals"] > 0 and stats["primal_steps"] > 0, stats
+    obj = eng.obj(dst)
+    np.testing.assert_allclose(obj, exp_obj, rtol=RTOL, atol=1e-9)
+    _check_identities(model, V, obj, eng.dual(dst, model.w_first, q), eng.primal(dst, model.y_first, q))
+    eng.close()
