@@ -162,7 +162,9 @@ def main():
     # Dominant kernel: k_flush, one pass over the tableau of every LP that has pivots pending (delayed update: up to 6 pivots
     # are selected on vectors, then applied together).  Unit = one (LP, pass); algorithmic bytes per unit = one read + one
     # write of the eliminated tableau, 16*(m+r+1)*(n+2) -- SURVEY 8d K3's figure, which the reference algorithm pays per PIVOT.
-    alg_bytes_per_pass = 16.0 * (m + r + 1) * (n + 2)
+    dims = eng.lp_dims()                 # (rows of A that were single-variable bounds are not in the LP)
+    m_lp = dims["M"] - q - r - 1
+    alg_bytes_per_pass = 16.0 * (m_lp + r + 1) * (n + 2)
     launches = max(lockstep, 1)
     achieved = (passes * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     per_pivot_equiv = (pivots * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
@@ -202,7 +204,7 @@ def main():
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s (q=%d, n=%d, m=%d dense covering VLP, seed per SURVEY 8d)" % (args.workload, q, n, m),
-                       "lp_rows_cols": [m + q + r + 1, n + q + 1], "batch_per_gpu": B, "global_batch": B * world,
+                       "lp_rows_cols": [dims["M"], dims["N"]], "rows_folded_by_presolve": dims["rows_folded"], "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "vertex batch sharded over %d GPU(s), one all_gather of cut records per step" % world,
                        "lp_poly_overlap": pipe is not None,
                        "tableau_slot_bytes": slot_bytes, "pool_slots": 4 * B + 64, "ramp_steps_untimed": ramp_steps},

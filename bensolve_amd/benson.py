@@ -138,6 +138,12 @@ class BensonEngine:
         check(self.lib.bslv_benson_apply_ctx(self.h, ctx, len(records), records.ctypes.data, stats))
         return dict(zip(("lps", "cuts", "redundant", "confirmed", "failed"), list(stats)))
 
+    def lp_dims(self):
+        M, N, f = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.lib.bslv_benson_lp_dims.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 3
+        check(self.lib.bslv_benson_lp_dims(self.h, ctypes.byref(M), ctypes.byref(N), ctypes.byref(f)))
+        return dict(M=M.value, N=N.value, rows_folded=f.value)
+
     def totals(self):
         a, b, c = ctypes.c_long(), ctypes.c_long(), ctypes.c_long()
         check(self.lib.bslv_benson_totals(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))

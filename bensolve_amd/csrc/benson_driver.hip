@@ -470,6 +470,14 @@ int bslv_benson_set_policy(bslv_benson *h, int policy)
     h->policy = policy;
     return 0;
 }
+int bslv_benson_lp_dims(const bslv_benson *h, int *M, int *N, int *rows_folded)
+{
+    if (!h) return BSLV_E_ARG;
+    if (M) *M = h->M;
+    if (N) *N = h->N;
+    if (rows_folded) *rows_folded = h->rows_folded;
+    return 0;
+}
 int bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots)
 {
     if (!h) return BSLV_E_ARG;

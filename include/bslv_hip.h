@@ -183,6 +183,9 @@ int  bslv_benson_unprocessed_left(const bslv_benson *h);
 /* batch selection: 1 = newest vertices first (default), 2 = spread evenly over the unprocessed queue */
 int  bslv_benson_set_policy(bslv_benson *h, int policy);
 int  bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots);
+/* size of the P2 model after the driver's presolve (rows of A with a single non-zero become column bounds and leave the
+ * LP; the hypercube rows of S-degenerate, ex/example10.m:21-24): M x N of init_P2 (bslv_algs.c:574-664) minus the folded rows */
+int  bslv_benson_lp_dims(const bslv_benson *h, int *M, int *N, int *rows_folded);
 bslv_poly *bslv_benson_poly(bslv_benson *h);
 bslv_lpq  *bslv_benson_lp(bslv_benson *h);
 
