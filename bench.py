@@ -56,6 +56,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    from bensolve_amd._lib import load_library as _load_lib
+    _rc = _load_lib().bslv_set_device(local_rank)      # the engine allocates on the thread's current HIP device: make it explicit
+    if _rc != 0:
+        raise SystemExit("bslv_set_device(%d) failed: %d" % (local_rank, _rc))
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)

@@ -894,6 +894,15 @@ int bslv_device_count(void)
     return n;
 }
 
+int bslv_set_device(int device)
+{
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { set_error("bslv_set_device: device %d of %d", device, n); return BSLV_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
 int bslv_device_info(char *name, int name_len, int *cus, size_t *mem_bytes)
 {
     int dev = 0;

@@ -39,6 +39,9 @@ enum { BSLV_LP_INFEASIBLE = 0, BSLV_LP_UNBOUNDED = 1, BSLV_LP_UNEXPECTED = 2, BS
 
 const char *bslv_last_error(void);
 int bslv_device_count(void);
+/* the GPU the calling thread's engines live on from now (one process per GPU: LOCAL_RANK); engines are created on the
+ * current HIP device of the thread that creates them */
+int bslv_set_device(int device);
 /* name / CU count / total global memory of the device the calling thread uses */
 int bslv_device_info(char *name, int name_len, int *cus, size_t *mem_bytes);
 
