@@ -29,6 +29,8 @@ static double ms_since(clk::time_point t0) { return std::chrono::duration<double
 struct bslv_benson {
     int m = 0, n = 0, q = 0, r = 0, M = 0, N = 0;     // m: rows of A left after the presolve
     int rows_folded = 0;                              // singleton rows of A turned into column bounds
+    bool hom = false;                                 // homogeneous problem (phases 0 and 1)
+    std::vector<double> eta;                          // q: coefficients of the last row (eta.y <= 1 when hom)
     double eps = 1e-7;
     std::vector<double> R, c;           // q x r (generators as columns), q
     bslv_lpq *lp = nullptr;
@@ -88,6 +90,17 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
                        const char *ctype, const double *clb, const double *cub,
                        const double *R, int r, const double *c, double eps, int pool_slots)
 {
+    return bslv_benson_create_ex(out, m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, R, r, c, nullptr, 0, eps, pool_slots);
+}
+
+// hom != 0: the HOMOGENEOUS problem of phases 0 and 1 (init_P2(..., HOMOGENEOUS), bslv_algs.c:574-664): every bound of the
+// VLP becomes 0 and double-bounded turns into fixed (lp_set_rows_hom / lp_set_cols_hom, bslv_lp.c:34-43,118-134), the columns
+// of R are the generators Z of the dual ordering cone, and the last row reads eta.y <= 1 (eta may be NULL = 0: phase 0).
+int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *A, const double *P,
+                          const char *rtype, const double *rlb, const double *rub,
+                          const char *ctype, const double *clb, const double *cub,
+                          const double *R, int r, const double *c, const double *eta, int hom, double eps, int pool_slots)
+{
     if (!out || m < 1 || n < 1 || q < 2 || r < 1 || !A || !P || !rtype || !ctype || !R || !c || pool_slots < 4) {
         set_error("bslv_benson_create: bad argument");
         return BSLV_E_ARG;
@@ -97,15 +110,18 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
     // ex/example10.m:21-24 states its box the same way).  It is folded into the column's bounds and dropped from the LP: the
     // LP loses a row, and the column becomes boxed, which is what the bound flipping ratio test of the LP engine works on.
     // Only y* (duals of the q objective rows) and y leave the LP layer in phase 2, so no dual of a folded row is ever read.
+    auto vlp_bounds = [hom](char t, double lb, double ub, double *lo, double *up) {
+        if (hom) bounds_of(t == 'd' ? 's' : t, 0.0, 0.0, lo, up); else bounds_of(t, lb, ub, lo, up);
+    };
     std::vector<double> clo(n), cup(n);
-    for (int j = 0; j < n; j++) bounds_of(ctype[j], clb ? clb[j] : 0, cub ? cub[j] : 0, &clo[j], &cup[j]);
+    for (int j = 0; j < n; j++) vlp_bounds(ctype[j], clb ? clb[j] : 0, cub ? cub[j] : 0, &clo[j], &cup[j]);
     std::vector<int> keep;
     keep.reserve(m);
     for (int i = 0; i < m; i++) {
         int nz = 0, jj = -1;
         for (int j = 0; j < n && nz < 2; j++) if (A[(size_t)i * n + j] != 0.0) { nz++; jj = j; }
         double lo_i, up_i;
-        bounds_of(rtype[i], rlb ? rlb[i] : 0, rub ? rub[i] : 0, &lo_i, &up_i);
+        vlp_bounds(rtype[i], rlb ? rlb[i] : 0, rub ? rub[i] : 0, &lo_i, &up_i);
         if (nz == 1 && !getenv("BSLV_NO_PRESOLVE")) {
             const double a = A[(size_t)i * n + jj];
             double lo = a > 0 ? lo_i / a : up_i / a, up = a > 0 ? up_i / a : lo_i / a;
@@ -134,10 +150,14 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
         for (int k = 0; k < q; k++) L[(size_t)(m + q + i) * N + n + k] = R[(size_t)k * r + i];
         L[(size_t)(m + q + i) * N + n + q] = -1.0;
     }
-    for (int i = 0; i < m; i++) bounds_of(rtype[keep[i]], rlb ? rlb[keep[i]] : 0, rub ? rub[keep[i]] : 0, &lo[i], &up[i]);
+    for (int i = 0; i < m; i++) vlp_bounds(rtype[keep[i]], rlb ? rlb[keep[i]] : 0, rub ? rub[keep[i]] : 0, &lo[i], &up[i]);
     for (int k = 0; k < q; k++) { lo[m + k] = 0; up[m + k] = 0; }
     for (int i = 0; i < r; i++) { lo[m + q + i] = -INFINITY; up[m + q + i] = 0; }
-    lo[m + q + r] = -INFINITY; up[m + q + r] = INFINITY;
+    lo[m + q + r] = -INFINITY; up[m + q + r] = hom ? 1.0 : INFINITY;            // eta.y <= 1 | free (bslv_algs.c:636-649)
+    if (eta) for (int k = 0; k < q; k++) L[(size_t)(m + q + r) * N + n + k] = eta[k];
+    h->hom = hom != 0;
+    h->eta.assign(q, 0.0);
+    if (eta) h->eta.assign(eta, eta + q);
     for (int j = 0; j < n; j++) { lo[M + j] = clo[j]; up[M + j] = cup[j]; }
     for (int j = n; j < N; j++) { lo[M + j] = -INFINITY; up[M + j] = INFINITY; }
     cost[N] = 1.0;
@@ -342,6 +362,11 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
     if ((rc = bslv_lpq_get_dual(h->lp, nl, dst.data(), h->m, q, ww.data()))) return rc;                 // bslv_algs.c:1050
     if ((rc = bslv_lpq_get_primal(h->lp, nl, dst.data(), h->M + h->n, q, yy.data()))) return rc;        // :1055
     if ((rc = bslv_lpq_get_obj(h->lp, nl, dst.data(), zz.data()))) return rc;                           // :1056
+    std::vector<double> alpha;
+    if (h->hom) {                                                                                       // dual of the eta row (:879)
+        alpha.resize(nl);
+        if ((rc = bslv_lpq_get_dual(h->lp, nl, dst.data(), h->m + q + r, 1, alpha.data()))) return rc;
+    }
     long piv = 0;
     for (int k = 0; k < nl; k++) {
         double *rec = records + (size_t)k * RL;
@@ -349,8 +374,13 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
         rec[1] = st[k];
         rec[3] = zz[k];
         double last = 0;
-        for (int kk = 0; kk < q - 1; kk++) rec[4 + kk] = ww[(size_t)k * q + kk];
-        for (int kk = 0; kk < q; kk++) last += yy[(size_t)k * q + kk] * ww[(size_t)k * q + kk];         // y*_q = w.Px (:1059-1062)
+        if (h->hom) {                                                                                   // phase 1: y* = (w + alpha eta, alpha) (:880-883)
+            for (int kk = 0; kk < q - 1; kk++) rec[4 + kk] = ww[(size_t)k * q + kk] + alpha[k] * h->eta[kk];
+            last = alpha[k];
+        } else {
+            for (int kk = 0; kk < q - 1; kk++) rec[4 + kk] = ww[(size_t)k * q + kk];
+            for (int kk = 0; kk < q; kk++) last += yy[(size_t)k * q + kk] * ww[(size_t)k * q + kk];     // y*_q = w.Px (:1059-1062)
+        }
         rec[4 + q - 1] = last;
         rec[2] = (st[k] == BSLV_LP_OPTIMAL && zz[k] > h->eps) ? 1.0 : 0.0;                              // :1063
         rec[4 + q] = h->rank;

@@ -75,6 +75,12 @@ static int write_lists(const char *path, int nrow, const int *rowmap, const int 
  * counts (may be NULL): [0] primal points, [1] primal directions, [2] dual points, [3] dual directions */
 int bslv_sol_write(bslv_poly *poly, const char *base, const char *suffix, int optdir, long *counts)
 {
+    return bslv_sol_write2(poly, base, suffix, optdir == -1, optdir == -1, counts);
+}
+
+/* negate_primal / negate_dual_last: the sign changes of poly_trans_primal (bslv_algs.c:221-229) for max problems and c_q < 0 */
+int bslv_sol_write2(bslv_poly *poly, const char *base, const char *suffix, int negate_primal, int negate_dual_last, long *counts)
+{
     const int d = bslv_poly_dim(poly), nv = bslv_poly_nprimal(poly), nf = bslv_poly_ndual(poly);
     int rc = bslv_poly_dual_adjacency(poly);                    /* bslv_algs.c:1144 */
     if (rc) return rc;
@@ -92,12 +98,12 @@ int bslv_sol_write(bslv_poly *poly, const char *base, const char *suffix, int op
     for (int f = 0; f < nf; f++) { dmap[f] = du[f] ? nd++ : -1; if (du[f]) cnt[di[f] ? 3 : 2]++; }
     for (int i = 0; i < nv; i++) {
         if (!pu[i]) continue;
-        if (optdir == -1) for (int k = 0; k < d; k++) X[(size_t)i * d + k] = -X[(size_t)i * d + k];
+        if (negate_primal) for (int k = 0; k < d; k++) X[(size_t)i * d + k] = -X[(size_t)i * d + k];
         chop_norm(X + (size_t)i * d, d, pi[i]);
     }
     for (int f = 0; f < nf; f++) {
         if (!du[f]) continue;
-        if (optdir == -1) Y[(size_t)f * d + d - 1] = -Y[(size_t)f * d + d - 1];
+        if (negate_dual_last) Y[(size_t)f * d + d - 1] = -Y[(size_t)f * d + d - 1];
         chop_norm(Y + (size_t)f * d, d, di[f]);
     }
     char path[1024];

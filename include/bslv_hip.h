@@ -169,6 +169,14 @@ int  bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A,
                         const char *rtype, const double *rlb, const double *rub,
                         const char *ctype, const double *clb, const double *cub,
                         const double *R, int r, const double *c, double eps, int pool_slots);
+/* the same with the homogeneous problem of phases 0 and 1 (init_P2(..., HOMOGENEOUS), bslv_algs.c:574-664): hom != 0 zeroes
+ * every bound of the VLP ('d' becomes fixed; lp_set_rows_hom / lp_set_cols_hom, bslv_lp.c:118-134), R holds the generators Z
+ * of the dual ordering cone and the last row reads eta.y <= 1 (eta NULL = 0).  The cut of a vertex is then
+ * y* = (w + alpha eta, alpha), alpha = dual of that row (phase1_primal, bslv_algs.c:876-883). */
+int  bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *A, const double *P,
+                           const char *rtype, const double *rlb, const double *rub,
+                           const char *ctype, const double *clb, const double *cub,
+                           const double *R, int r, const double *c, const double *eta, int hom, double eps, int pool_slots);
 void bslv_benson_destroy(bslv_benson *h);
 int  bslv_benson_start(bslv_benson *h, int *vlp_status /* 0 ok, 1 infeasible, 2 unbounded */);
 int  bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int *n_local, int *n_total);
@@ -193,6 +201,36 @@ bslv_poly *bslv_benson_poly(bslv_benson *h);
 bslv_lpq  *bslv_benson_lp(bslv_benson *h);
 
 /* ------------------------------------------------------------------------------------------
+ * 4b. The callers around phase 2: ordering cone data (sol_init, bslv_vlp.c:599-864), cone_vertenum
+ *     (bslv_algs.c:331-407), phase 0 (bslv_algs.c:673-800), phase 1 of the primal algorithm (bslv_algs.c:811-933) and the
+ *     sequence of bslv_main.c:236-345.  Matrices of generators are q x k row-major with the generators as columns
+ *     (M[j*k + i] = component j of generator i), as sol->Z / sol->R / vlp->gen are.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bslv_vlp_info {
+    int q, o, p, r, h;            /* soltype: generators of C (o), of C* (p), of the dual recession cone (r), of the recession cone (h) */
+    int c_dir;                    /* +1 c_q > 0, -1 c_q < 0 (bslv_vlp.c:690-776) */
+    int negate_primal;            /* poly_trans_primal (bslv_algs.c:221-229): the result writers negate y ... */
+    int negate_dual_last;         /* ... and y*_q */
+    long lps, steps;              /* LPs solved in all phases, outer iterations */
+    double *c, *eta, *R, *H, *Y, *Z;   /* malloc'ed: c as written to _c.sol (before the sign change of :844-853); free with bslv_vlp_info_free */
+    char message[160];            /* the reference's message when the status is not "optimal" */
+} bslv_vlp_info;
+/* cone_kind 0 default (R^q_+), 1 `gen` generates C, 2 `gen` generates C* (vlp->cone_gen); c_in: q or NULL (vlp->c).
+ * vlp_status (sol->status, bslv_main.h:103): 1 infeasible, 2 unbounded, 3 no vertex, 4 optimal, 5 input error.
+ * With status 4 *engine_out is the finished phase-2 engine (bslv_benson_poly(engine) is the result; destroy it). */
+int  bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P,
+                           const char *rtype, const double *rlb, const double *rub,
+                           const char *ctype, const double *clb, const double *cub,
+                           int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
+                           int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
+                           int batch, bslv_benson **engine_out, int *vlp_status, bslv_vlp_info *info /* may be NULL */);
+void bslv_vlp_info_free(bslv_vlp_info *info);
+/* cone_vertenum: prim = the non-redundant generators among gen (dim x n_prim), dual = generators of the dual cone
+ * (dim x n_dual); malloc'ed, free with bslv_free.  rc_out 1: the cone has no interior (poly__intl_apprx failed). */
+int  bslv_cone_vertenum(const double *gen, int n_in, int dim, double **prim, int *n_prim, double **dual, int *n_dual, int *rc_out);
+void bslv_free(void *p);
+
+/* ------------------------------------------------------------------------------------------
  * 5. Host side that stays C: the .vlp reader (vlp_init, bslv_vlp.c:275-588; kept file-format
  *    contract) and the result-file writers (poly_output, bslv_algs.c:50-144; formats of
  *    bslv_poly.c:341-414).  Struct bslv_vlp: bensolve_amd/csrc/host/bslv_host.h.
@@ -202,6 +240,8 @@ int  bslv_vlp_read(const char *path, struct bslv_vlp **out, int *err_line);
 void bslv_vlp_free(struct bslv_vlp *v);
 const char *bslv_vlp_message(const struct bslv_vlp *v);
 int  bslv_sol_write(bslv_poly *poly, const char *base, const char *suffix, int optdir, long *counts /* 4, may be NULL */);
+/* the same with the two sign changes of poly_trans_primal (bslv_algs.c:221-229) spelled out (bslv_vlp_info) */
+int  bslv_sol_write2(bslv_poly *poly, const char *base, const char *suffix, int negate_primal, int negate_dual_last, long *counts);
 
 #ifdef __cplusplus
 }

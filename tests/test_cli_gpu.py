@@ -62,11 +62,56 @@ def test_cli_files_match_hybrid(tmp_path, m, n, q, seed, sense):
         assert sum(map(len, adj)) == sum(map(len, radj)) and sum(map(len, incp)) == sum(map(len, rinc))
 
 
-def test_cli_refuses_unbounded_mode_and_bad_file(tmp_path):
+def test_cli_reports_bad_file(tmp_path):
     path = os.path.join(tmp_path, "p.vlp")
-    synth.write_vlp(synth.covering_vlp(6, 4, 2, 1), path)
-    r = subprocess.run([CLI, path], capture_output=True, text=True)
-    assert r.returncode == 2 and "not built yet" in r.stdout
     open(path, "w").write("p vlp min 1 1 1 1 1\na 9 1 1\ne\n")
     r = subprocess.run([CLI, path, "-b"], capture_output=True, text=True)
     assert r.returncode == 1 and "line 2" in r.stdout
+
+
+# ---- all phases (sol_init, phase 0, phase 1, phase 2) natively: the example suite against the committed outputs of the
+#      hybrid (the reference's driver + polyhedron code + oracle LP), tests/golden/hybrid.npz ----
+import json
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "hybrid.npz"))
+EXDIR = os.path.join(ROOT, "tests", "golden", "ex")
+
+
+def _gold_rows(t, X):
+    X = X.copy()
+    for i in np.nonzero(t == 0)[0]:
+        X[i] /= np.abs(X[i]).max()
+    key = np.round(X, 6) + 0.0
+    o = np.lexsort([key[:, j] for j in range(X.shape[1] - 1, -1, -1)] + [1 - t])
+    return t[o], X[o]
+
+
+@pytest.mark.parametrize("ex", ["ex01", "ex05", "ex06", "ex08", "ex11"])
+def test_cli_all_phases_match_hybrid_goldens(tmp_path, ex):
+    """ex01: unbounded upper image (phases 0/1 find the recession cone); ex05 / ex08: ordering cone given by generators,
+    ex06: by generators of its dual, a max problem; ex11: q = 5."""
+    base = os.path.join(tmp_path, ex)
+    r = subprocess.run([CLI, os.path.join(EXDIR, ex + ".vlp"), "-m", "2", "-B", "64", "-o", base], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for side in ("p", "d"):
+        t, X, _ = read_img(base + "_img_%s.sol" % side)
+        gt, gX = _gold_rows(GOLD["%s/%s_type" % (ex, side)], GOLD["%s/%s" % (ex, side)])
+        assert np.array_equal(t, gt), (ex, side, r.stdout)
+        np.testing.assert_allclose(X, gX, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("ex,frag", [("ex02", "VLP is infeasible"), ("ex03", "no vertex"), ("ex04", "totally unbounded")])
+def test_cli_documented_outcomes(tmp_path, ex, frag):
+    # ex/example02.m, example03.m, example04.m state these outcomes (phase 2 part 1, phase 0, phase 0)
+    r = subprocess.run([CLI, os.path.join(EXDIR, ex + ".vlp"), "-m", "1", "-o", os.path.join(tmp_path, ex)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and frag in r.stdout, r.stdout + r.stderr
+
+
+def test_cli_ex01_known_answer(tmp_path):
+    """ex/example01.m: the feasible vertices map to (-6,6), (0,4), (6,6); the upper image has
+    the vertices (0,4) and (-6,6) and the extreme directions (1,0) and (-1,1) (SURVEY.md 8c known-answer test)."""
+    base = os.path.join(tmp_path, "ex01")
+    r = subprocess.run([CLI, os.path.join(EXDIR, "ex01.vlp"), "-m", "0", "-o", base], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    t, X, _ = read_img(base + "_img_p.sol")
+    got = sorted((int(a), round(float(x), 9) + 0.0, round(float(y), 9) + 0.0) for a, (x, y) in zip(t, X))
+    assert got == sorted([(1, 0.0, 4.0), (1, -6.0, 6.0), (0, 1.0, 0.0), (0, -1.0, 1.0)])
