@@ -48,6 +48,7 @@ struct PivDesc { int r, q; double p, pbeta, enter_val; };
 
 struct LpView {
     int M, N, ld, Mp1, Mp1p, vfirst, vcnt, maxit, bland_after, trace, stall_limit;
+    int objmode, cfirst, ccnt;  // solve_batch_obj: the LPs of the batch differ in the cost of variables cfirst .. cfirst+ccnt-1 (BatchView::cvals)
     size_t slotT;
     double pert_scale;          // multiplies the cost perturbation (1; tests raise it to force the clean-up paths)
     double *T, *beta, *xN;
@@ -70,6 +71,7 @@ struct BatchView {
     // Extended selection (k_select<true>): cost perturbation against dual degenerate stalling, primal clean-up afterwards
     double *dper;               // [B][ld]       perturbed reduced costs (the ratio tests use them while PF_PERT is set)
     int *pflags, *stall;        // PF_* bits; consecutive degenerate pivots
+    const double *cvals;        // [B][ccnt] objective coefficients (objmode)
     int *xstat;                 // [4] of the batch: iterations with bound switches, perturbations, primal steps, removals that left wrong signs
     int *work, *nwork;      // LPs whose tableau k_flush passes over in a round (k_list_pending), their number per round
 };
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
         else if (isinf(up)) st = NS_L;
         else {
             // boxed: sit at the bound that keeps the reduced cost dual feasible
-            double dj = drow_s[j];
+            double dj = L.objmode ? 0.0 : drow_s[j];       // (new objective: stay where the parent was, that is primal feasible)
             if (dj < -TOL_DJ) st = NS_U;
             else if (dj > TOL_DJ) st = NS_L;
             else if (st != NS_L && st != NS_U) st = NS_L;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
         // reduced cost cannot be repaired by a flip (the reference's GLPK would run its primal phase)
         {
             double dj = drow_s[j];
-            if ((st == NS_F && fabs(dj) > 1e-7) || (st == NS_L && dj < -1e-7) || (st == NS_U && dj > 1e-7)) dual_infeasible = 1;
+            if (!L.objmode && ((st == NS_F && fabs(dj) > 1e-7) || (st == NS_L && dj < -1e-7) || (st == NS_U && dj > 1e-7))) dual_infeasible = 1;
         }
         { const unsigned char a = L.art[k]; if ((st == NS_L && (a & 1)) || (st == NS_U && (a & 2))) bigm = 1; }
         nh_d[j] = k;
@@ -133,7 +135,24 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
     }
     {   // working copy of the reduced-cost row (k_select keeps it up to date between passes over the tableau)
         double *dc = Bv.dcur + (size_t)b * L.ld;
-        for (int j = threadIdx.x; j < L.ld; j += NT) dc[j] = j < L.N ? drow_s[j] : 0.0;
+        if (!L.objmode) for (int j = threadIdx.x; j < L.ld; j += NT) dc[j] = j < L.N ? drow_s[j] : 0.0;
+        else {
+            // new objective: d_j = c_{nh[j]} + sum over the basic cost-carrying variables c_k T[row of k][j], from the parent's
+            // tableau; it also becomes row M of the new slot (k_init takes beta_M = d . x_N from there)
+            const double *Ts = L.T + (size_t)src * L.slotT;
+            double *rowM = L.T + (size_t)dst * L.slotT + (size_t)L.M * L.ld;
+            const double *cv = Bv.cvals + (size_t)b * L.ccnt;
+            for (int j = threadIdx.x; j < L.ld; j += NT) {
+                double v = 0.0;
+                if (j < L.N) {
+                    const int kj = nh_s[j] - L.cfirst;
+                    if (kj >= 0 && kj < L.ccnt) v = cv[kj];
+                    for (int t = 0; t < L.ccnt; t++) { const int pr = pos_s[L.cfirst + t]; if (pr >= 0) v = fma(cv[t], Ts[(size_t)pr * L.ld + j], v); }
+                }
+                dc[j] = v;
+                rowM[j] = v;
+            }
+        }
     }
     dual_infeasible = __syncthreads_or(dual_infeasible);
     bigm = __syncthreads_or(bigm);
@@ -143,9 +162,9 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
         Bv.mode[b] = MODE_NONE;
         Bv.verified[b] = 1 | (bigm ? 2 : 0);   // k_init recomputes beta from scratch
         Bv.npend[b] = 0;
-        Bv.pflags[b] = 0;
+        Bv.pflags[b] = L.objmode ? PF_PRIMAL : 0;       // a new objective on a primal feasible basis: primal simplex steps
         Bv.stall[b] = 0;
-        Bv.flushed[b] = src == dst;            // (in place: the slot already holds the tableau)
+        Bv.flushed[b] = (src == dst) || L.objmode;      // (objmode: the tableau is copied up front, see solve_batch)            // (in place: the slot already holds the tableau)
     }
 }
 
@@ -168,14 +187,14 @@ __global__ __launch_bounds__(NT) void k_init(LpView L, BatchView Bv, int B)
     for (int rr = wave; rr < TR; rr += NT / WAVE) {
         int i = blockIdx.x * TR + rr;
         if (i >= L.Mp1) break;
-        const double2 *s = reinterpret_cast<const double2 *>(Ts + (size_t)i * L.ld);
+        const double2 *s = reinterpret_cast<const double2 *>(((L.objmode && i == L.M) ? Td : Ts) + (size_t)i * L.ld);   // (objmode: k_prep wrote the new row M)
         double2 *d = reinterpret_cast<double2 *>(Td + (size_t)i * L.ld);
         const double2 *x2 = reinterpret_cast<const double2 *>(xN);
         double acc = 0.0;
         for (int j2 = lane; j2 < ld2; j2 += WAVE) {
             double2 v = s[j2];
             double2 x = x2[j2];
-            if (copy && i == L.M) d[j2] = v;      // only the reduced-cost row: the first pass streams the rest from the parent (k_flush)
+            if (copy && i == L.M && !L.objmode) d[j2] = v;      // only the reduced-cost row: the first pass streams the rest from the parent (k_flush)
             acc = fma(v.x, x.x, acc);
             acc = fma(v.y, x.y, acc);
         }
@@ -728,7 +747,7 @@ __global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, in
 __global__ void k_list_unpivoted(BatchView Bv, int B, int slot_of_count)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && Bv.iters[b] == 0 && Bv.src[b] != Bv.dst[b]) Bv.work[atomicAdd(&Bv.nwork[slot_of_count], 1)] = b;
+    if (b < B && (slot_of_count < 0 || !Bv.flushed[b]) && Bv.src[b] != Bv.dst[b]) Bv.work[atomicAdd(&Bv.nwork[slot_of_count < 0 ? -slot_of_count : slot_of_count], 1)] = b;
 }
 __global__ __launch_bounds__(NT) void k_copy_unpivoted(LpView L, BatchView Bv, int slot_of_count, int tiles)
 {
@@ -794,6 +813,7 @@ struct bslv_lpq {
     int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
     double *dper_d = nullptr; int *pflags_d = nullptr, *stall_d = nullptr, *xstat_d = nullptr;
+    double *cvals_d = nullptr; size_t cvals_cap = 0;     // objective coefficients of solve_batch_obj
     long last_ext[4] = {0, 0, 0, 0};
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
     size_t select_lds_max = 64 * 1024; // dynamic LDS of k_select<true> (candidate sort of the bound flipping ratio test)
@@ -983,7 +1003,7 @@ void bslv_lpq_destroy(bslv_lpq *h)
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
-    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d); fr(h->xstat_d);
+    fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d); fr(h->xstat_d); fr(h->cvals_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
     for (auto &e : h->evpool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1024,8 +1044,27 @@ int bslv_lpq_reset_slot(bslv_lpq *h, int slot)
     return 0;
 }
 
+static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo, const double *vup,
+                            int cfirst, int ccnt, const double *cvals, int *status, int *iters);
 int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo,
                          const double *vup, int *status, int *iters)
+{
+    return solve_batch_impl(h, B, src, dst, vlo, vup, 0, 0, nullptr, status, iters);
+}
+// The LPs of the batch differ in their OBJECTIVE (lp_set_obj_coeffs + lp_solve, bslv_lp.c:141-151,219: what phase2_dual
+// does per vertex, bslv_algs.c:1469-1477): cost costs[b*cost_cnt + t] on variable cost_first + t, 0 elsewhere (the engine's
+// own cost vector must be zero).  Bounds: those of the last solve_batch / set_bounds for the per-LP range (vlo/vup may be
+// NULL when the engine has no such range).  LP b starts from the basis of slot src[b], which must be primal feasible for
+// these bounds (an optimal slot of any objective is), and runs primal simplex steps.
+int bslv_lpq_solve_batch_obj(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo, const double *vup,
+                             int cost_first, int cost_cnt, const double *costs, int *status, int *iters)
+{
+    if (!h || cost_cnt < 1 || cost_first < 0 || cost_first + cost_cnt > h->L.M + h->L.N || !costs) { set_error("bslv_lpq_solve_batch_obj: bad argument"); return BSLV_E_ARG; }
+    for (size_t j = 0; j < h->cost.size(); j++) if (h->cost[j] != 0.0) { set_error("bslv_lpq_solve_batch_obj: the engine was created with a non-zero cost vector"); return BSLV_E_STATE; }
+    return solve_batch_impl(h, B, src, dst, vlo, vup, cost_first, cost_cnt, costs, status, iters);
+}
+static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo, const double *vup,
+                            int cfirst, int ccnt, const double *cvals, int *status, int *iters)
 {
     if (!h || B < 0 || (B > 0 && (!src || !dst)) || (B > 0 && h->L.vcnt > 0 && (!vlo || !vup))) {
         set_error("bslv_lpq_solve_batch: bad argument");
@@ -1049,6 +1088,12 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
         HIP_TRY(hipMemcpyAsync(h->vlo_d, vlo, (size_t)B * L.vcnt * sizeof(double), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(h->vup_d, vup, (size_t)B * L.vcnt * sizeof(double), hipMemcpyHostToDevice, s));
     }
+    L.objmode = cvals ? 1 : 0; L.cfirst = cfirst; L.ccnt = ccnt;
+    if (cvals) {
+        const size_t need = (size_t)B * ccnt;
+        if (need > h->cvals_cap) { if (h->cvals_d) (void)hipFree(h->cvals_d); h->cvals_d = nullptr; HIP_TRY(hipMalloc(&h->cvals_d, need * sizeof(double))); h->cvals_cap = need; }
+        HIP_TRY(hipMemcpyAsync(h->cvals_d, cvals, need * sizeof(double), hipMemcpyHostToDevice, s));
+    }
     if (const char *e = getenv("BSLV_UPD_GRID")) h->upd_grid = std::max(64, atoi(e));
     {   // one work-list length per lock-step iteration, zeroed here: no reset between iterations
         const int need = L.maxit + 64;
@@ -1057,13 +1102,19 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
     }
     HIP_TRY(hipMemsetAsync(h->xstat_d, 0, 4 * sizeof(int), s));
     BatchView bv = bview(h);
+    bv.cvals = h->cvals_d;
     const int tiles = (L.Mp1 + TR - 1) / TR;
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(NT), 0, s, L, bv, B);
+    if (L.objmode) {      // new objective: the tableau rows are copied up front (the reduced-cost row is rebuilt by k_prep, not streamed from the parent)
+        const int cnt_slot = L.maxit + 41;
+        hipLaunchKernelGGL(k_list_unpivoted, dim3((B + 255) / 256), dim3(256), 0, s, bv, B, -cnt_slot);
+        hipLaunchKernelGGL(k_copy_unpivoted, dim3(std::min(B * tiles, 2048)), dim3(NT), 0, s, L, bv, cnt_slot, tiles);
+    }
     hipLaunchKernelGGL(k_init, dim3(tiles, B), dim3(NT), 0, s, L, bv, B);
     HIP_TRY(hipGetLastError());
     const size_t lds = (size_t)KP * L.ld * sizeof(double);
     // bound flipping ratio test only where a variable has two finite, non-artificial bounds
-    bool bfrt = h->has_boxed;
+    bool bfrt = h->has_boxed || L.objmode;        // (the primal steps live in the extended selection)
     if (!bfrt && L.vcnt > 0)
         for (size_t k = 0; k < (size_t)B * L.vcnt && !bfrt; k++) bfrt = std::isfinite(vlo[k]) && std::isfinite(vup[k]) && vlo[k] < vup[k];
     if (getenv("BSLV_LP_EXT")) bfrt = atoi(getenv("BSLV_LP_EXT")) != 0;      // test hook: force the extended selection on / off

@@ -119,6 +119,21 @@ class LpEngine:
                                             vup.ctypes.data, status.ctypes.data, iters.ctypes.data))
         return status, iters
 
+    def solve_batch_obj(self, src, dst, cost_first, costs, vlo=None, vup=None):
+        """LPs that differ in the objective: costs[b, t] on variable cost_first + t (bslv_lpq_solve_batch_obj)."""
+        src = np.ascontiguousarray(src, np.int32)
+        dst = np.ascontiguousarray(dst, np.int32)
+        B = len(src)
+        costs = np.ascontiguousarray(costs, np.float64).reshape(B, -1)
+        vlo = np.ascontiguousarray(np.zeros((B, self.vcnt)) if vlo is None else vlo, np.float64).reshape(B, self.vcnt)
+        vup = np.ascontiguousarray(np.zeros((B, self.vcnt)) if vup is None else vup, np.float64).reshape(B, self.vcnt)
+        status = np.empty(B, np.int32)
+        iters = np.empty(B, np.int32)
+        self.lib.bslv_lpq_solve_batch_obj.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+        check(self.lib.bslv_lpq_solve_batch_obj(self.h, B, src.ctypes.data, dst.ctypes.data, vlo.ctypes.data, vup.ctypes.data,
+                                                cost_first, costs.shape[1], costs.ctypes.data, status.ctypes.data, iters.ctypes.data))
+        return status, iters
+
     def _get(self, fn, slots, first, cnt):
         slots = np.ascontiguousarray(slots, np.int32)
         out = np.empty((len(slots), cnt), np.float64)

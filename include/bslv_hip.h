@@ -78,6 +78,12 @@ int  bslv_lpq_reset_slot(bslv_lpq *h, int slot);
  * iters[b] the number of dual-simplex pivots.  Any of status/iters may be NULL. */
 int  bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst,
                           const double *vlo, const double *vup, int *status, int *iters);
+/* The LPs of the batch differ in their OBJECTIVE (lp_set_obj_coeffs + lp_solve, bslv_lp.c:141-151, 219-259, as phase2_dual
+ * drives them, bslv_algs.c:1469-1477): cost costs[b*cost_cnt + t] on variable cost_first + t, zero elsewhere (the engine must
+ * have been created with a zero cost vector).  LP b starts from the basis of slot src[b], which has to be primal feasible
+ * (any solved slot is: the bounds do not change) and runs primal simplex steps.  vlo/vup as in solve_batch. */
+int  bslv_lpq_solve_batch_obj(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo, const double *vup,
+                              int cost_first, int cost_cnt, const double *costs, int *status, int *iters);
 /* getters for solved slots: out[b*cnt + j] = value for variable first+j of slot[b]
  * (lp_primal_solution_rows/cols, lp_dual_solution_rows/cols, lp_obj_val: bslv_lp.c:261-308) */
 int  bslv_lpq_get_primal(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out);
