@@ -17,6 +17,7 @@ static void usage(void)
 {
     printf("Usage: bensolve_hip file.vlp [options]\n"
            "  -b, --bounded            assume the problem is bounded: skip phases 0 and 1 (R := Z)\n"
+           "  -a, --alg_phase2 ALG     primal (default) or dual: Benson's algorithm or its dual variant in phase 2\n"
            "  -E, --eps_phase1 EPS     epsilon of Benson's algorithm in phase 1 (default 1e-7)\n"
            "  -e, --eps_phase2 EPS     epsilon of Benson's algorithm in phase 2 (default 1e-7)\n"
            "  -o, --output_filename F  base name of the result files (default: input name up to the first '.')\n"
@@ -29,7 +30,7 @@ int main(int argc, char **argv)
 {
     if (argc < 2 || argv[1][0] == '-') { usage(); return 1; }
     const char *file = argv[1];
-    int bounded = 0, msg = 1, batch = 1024;
+    int bounded = 0, msg = 1, batch = 1024, dual2 = 0;
     double eps = 1e-7, eps1 = 1e-7;
     char base[1024] = "";
     for (int a = 2; a < argc; a++) {
@@ -40,6 +41,10 @@ int main(int argc, char **argv)
         else if (!strcmp(o, "-o") || !strcmp(o, "--output_filename")) snprintf(base, sizeof base, "%s", ARG());
         else if (!strcmp(o, "-m") || !strcmp(o, "--message_level")) msg = atoi(ARG());
         else if (!strcmp(o, "-B") || !strcmp(o, "--batch")) batch = atoi(ARG());
+        else if (!strcmp(o, "-a") || !strcmp(o, "--alg_phase2")) {
+            const char *v2 = ARG();
+            if (!strcmp(v2, "dual")) dual2 = 1; else if (!strcmp(v2, "primal")) dual2 = 0; else { printf("option --alg_phase2 (-a): invalid argument\n"); return 1; }
+        }
         else if (!strcmp(o, "-E") || !strcmp(o, "--eps_phase1")) { eps1 = atof(ARG()); if (!(eps1 > 0)) { printf("option --eps_phase1 (-E): invalid argument\n"); return 1; } }
         else if (!strcmp(o, "-h") || !strcmp(o, "--help")) { usage(); return 1; }
         else { printf("invalid option %s\n", o); return 1; }
@@ -64,8 +69,11 @@ int main(int argc, char **argv)
     bslv_vlp_info info;
     int st = 0;
     if (msg >= 1) printf("running ... \n");
-    int rc = bslv_vlp_solve_primal(v->m, v->n, q, v->A, v->P, v->rtype, v->rlb, v->rub, v->ctype, v->clb, v->cub,
-                                   v->optdir, v->cone_gen, v->gen, v->n_gen, v->c, bounded, 1e-8, 1e-8, eps1, eps, batch, &h, &st, &info);
+    bslv_poly *lower = NULL;
+    int rc = dual2 ? bslv_vlp_solve_dual2(v->m, v->n, q, v->A, v->P, v->rtype, v->rlb, v->rub, v->ctype, v->clb, v->cub,
+                                          v->optdir, v->cone_gen, v->gen, v->n_gen, v->c, bounded, 1e-8, 1e-8, eps1, eps, batch, &lower, &st, &info)
+                   : bslv_vlp_solve_primal(v->m, v->n, q, v->A, v->P, v->rtype, v->rlb, v->rub, v->ctype, v->clb, v->cub,
+                                           v->optdir, v->cone_gen, v->gen, v->n_gen, v->c, bounded, 1e-8, 1e-8, eps1, eps, batch, &h, &st, &info);
     if (rc) { printf("engine error %d: %s\n", rc, bslv_last_error()); return 3; }
     char cfile[1100];
     if (info.c) {                                                         /* bslv_vlp.c:833-842 */
@@ -77,15 +85,16 @@ int main(int argc, char **argv)
     if (msg >= 2 && !bounded) { printf("Result of phase 0: eta =\n "); for (int k = 0; k < q; k++) printf(" %.6g", info.eta[k]); printf("\n"); }
     double elapsed = now() - t0;
     long cnt[4], lps = 0, cuts = 0, piv = 0;
-    if ((rc = bslv_sol_write2(bslv_benson_poly(h), base, ".sol", info.negate_primal, info.negate_dual_last, cnt))) { printf("writing results failed (%d): %s\n", rc, bslv_last_error()); return 3; }
-    bslv_benson_totals(h, &lps, &cuts, &piv);
+    if ((rc = bslv_sol_write3(dual2 ? lower : bslv_benson_poly(h), base, ".sol", dual2, info.negate_primal, info.negate_dual_last, cnt))) { printf("writing results failed (%d): %s\n", rc, bslv_last_error()); return 3; }
+    if (h) bslv_benson_totals(h, &lps, &cuts, &piv);
     if (msg >= 1) {
         printf("CPU time            : %.4g %s.\n", elapsed >= 1 ? elapsed : elapsed * 1e3, elapsed >= 1 ? "s" : "ms");
         printf("Number of LPs solved: %ld.\n", info.lps);
     }
     if (msg >= 2) printf("outer iterations %ld, phase-2 cuts %ld, phase-2 pivots %ld; upper image: %ld points, %ld directions; lower image: %ld points, %ld directions\n",
                          info.steps, cuts, piv, cnt[0], cnt[1], cnt[2], cnt[3]);
-    bslv_benson_destroy(h);
+    if (h) bslv_benson_destroy(h);
+    if (lower) bslv_poly_destroy(lower);
     bslv_vlp_info_free(&info);
     bslv_vlp_free(v);
     return 0;

@@ -81,6 +81,15 @@ int bslv_sol_write(bslv_poly *poly, const char *base, const char *suffix, int op
 /* negate_primal / negate_dual_last: the sign changes of poly_trans_primal (bslv_algs.c:221-229) for max problems and c_q < 0 */
 int bslv_sol_write2(bslv_poly *poly, const char *base, const char *suffix, int negate_primal, int negate_dual_last, long *counts)
 {
+    return bslv_sol_write3(poly, base, suffix, 0, negate_primal, negate_dual_last, counts);
+}
+
+/* swap != 0: the polyhedron engine holds the LOWER image on its primal side and the upper image on its dual side (the dual
+ * algorithm, phase2_dual: poly_output(..., SWAP, ...), bslv_algs.c:1566-1573 with poly_trans_dual :232-240): the "_p" files
+ * are written from the dual side and the "_d" files from the primal side.  negate_upper: y -> -y on the upper image;
+ * negate_lower_last: y*_q -> -y*_q on the lower image. */
+int bslv_sol_write3(bslv_poly *poly, const char *base, const char *suffix, int swap, int negate_primal, int negate_dual_last, long *counts)
+{
     const int d = bslv_poly_dim(poly), nv = bslv_poly_nprimal(poly), nf = bslv_poly_ndual(poly);
     int rc = bslv_poly_dual_adjacency(poly);                    /* bslv_algs.c:1144 */
     if (rc) return rc;
@@ -98,23 +107,35 @@ int bslv_sol_write2(bslv_poly *poly, const char *base, const char *suffix, int n
     for (int f = 0; f < nf; f++) { dmap[f] = du[f] ? nd++ : -1; if (du[f]) cnt[di[f] ? 3 : 2]++; }
     for (int i = 0; i < nv; i++) {
         if (!pu[i]) continue;
-        if (negate_primal) for (int k = 0; k < d; k++) X[(size_t)i * d + k] = -X[(size_t)i * d + k];
+        if (!swap && negate_primal) for (int k = 0; k < d; k++) X[(size_t)i * d + k] = -X[(size_t)i * d + k];
+        if (swap && negate_dual_last) X[(size_t)i * d + d - 1] = -X[(size_t)i * d + d - 1];
         chop_norm(X + (size_t)i * d, d, pi[i]);
     }
     for (int f = 0; f < nf; f++) {
         if (!du[f]) continue;
-        if (negate_dual_last) Y[(size_t)f * d + d - 1] = -Y[(size_t)f * d + d - 1];
+        if (!swap && negate_dual_last) Y[(size_t)f * d + d - 1] = -Y[(size_t)f * d + d - 1];
+        if (swap && negate_primal) for (int k = 0; k < d; k++) Y[(size_t)f * d + k] = -Y[(size_t)f * d + k];
         chop_norm(Y + (size_t)f * d, d, di[f]);
     }
     char path[1024];
     int err = 0;
 #define P(sfx) (snprintf(path, sizeof path, "%s%s%s", base, sfx, suffix), path)
-    err |= write_img(P("_img_p"), nv, d, pu, pi, X);
-    err |= write_img(P("_img_d"), nf, d, du, di, Y);
-    err |= write_lists(P("_adj_p"), np, pmap, pmap, ne, E, 0, 1);
-    err |= write_lists(P("_adj_d"), nd, dmap, dmap, nde, DE, 0, 1);
-    err |= write_lists(P("_inc_p"), nd, dmap, pmap, ni, I, 1, 0);     /* row = facet, entries = vertices on it */
-    err |= write_lists(P("_inc_d"), np, pmap, dmap, ni, I, 0, 0);     /* row = vertex, entries = facets through it */
+    if (!swap) {
+        err |= write_img(P("_img_p"), nv, d, pu, pi, X);
+        err |= write_img(P("_img_d"), nf, d, du, di, Y);
+        err |= write_lists(P("_adj_p"), np, pmap, pmap, ne, E, 0, 1);
+        err |= write_lists(P("_adj_d"), nd, dmap, dmap, nde, DE, 0, 1);
+        err |= write_lists(P("_inc_p"), nd, dmap, pmap, ni, I, 1, 0);     /* row = facet, entries = vertices on it */
+        err |= write_lists(P("_inc_d"), np, pmap, dmap, ni, I, 0, 0);     /* row = vertex, entries = facets through it */
+    } else {
+        err |= write_img(P("_img_p"), nf, d, du, di, Y);
+        err |= write_img(P("_img_d"), nv, d, pu, pi, X);
+        err |= write_lists(P("_adj_p"), nd, dmap, dmap, nde, DE, 0, 1);
+        err |= write_lists(P("_adj_d"), np, pmap, pmap, ne, E, 0, 1);
+        err |= write_lists(P("_inc_p"), np, pmap, dmap, ni, I, 0, 0);
+        err |= write_lists(P("_inc_d"), nd, dmap, pmap, ni, I, 1, 0);
+        { long t0 = cnt[0], t1 = cnt[1]; cnt[0] = cnt[2]; cnt[1] = cnt[3]; cnt[2] = t0; cnt[3] = t1; }
+    }
 #undef P
     if (counts) memcpy(counts, cnt, sizeof cnt);
     free(pu); free(pi); free(du); free(di); free(X); free(Y); free(E); free(I); free(DE); free(pmap); free(dmap);

@@ -280,6 +280,108 @@ static int phase1_primal(const Problem &pb, Sol &S, double eps_phase1, double ep
     return done(0);
 }
 
+
+// ---- phase 2, dual algorithm (bslv_algs.c:1381-1592): outer approximation of the LOWER image.  Each vertex y* of the current
+//      approximation gives the weights w(y*) = (y*_1..y*_{q-1}, 1 - sum c_i y*_i) of P1(w): min w.y, y = Px, x feasible
+//      (init_P1, :1186-1238); its optimal y cuts y* off when y*_q - w.y > eps.  The LPs of a batch differ only in the
+//      objective: bslv_lpq_solve_batch_obj, all warm-started from the first solved basis (slot 0).
+//      status: 0 ok, 1 VLP_INFEASIBLE, 2 VLP_UNBOUNDED.  The polyhedron (primal side = lower image) is handed to the caller. ----
+static int phase2_dual(const Problem &pb, const Sol &S, double eps, int batch, bslv_poly **poly_out, int *status, long *lps, long *steps)
+{
+    *status = 0; *poly_out = nullptr;
+    const int m = pb.m, n = pb.n, q = pb.q, M = m + q, N = n + q;
+    std::vector<double> L((size_t)M * N, 0.0), lo(M + N), up(M + N), cost(N + 1, 0.0);
+    for (int i = 0; i < m; i++) memcpy(&L[(size_t)i * N], pb.A + (size_t)i * n, n * sizeof(double));
+    for (int k = 0; k < q; k++) {
+        for (int j = 0; j < n; j++) L[(size_t)(m + k) * N + j] = -pb.P[(size_t)k * n + j];
+        L[(size_t)(m + k) * N + n + k] = 1.0;
+    }
+    auto bnd = [](char t, double lb, double ub, double *l, double *u) {
+        *l = (t == 'l' || t == 'd' || t == 's') ? lb : -INFINITY;
+        *u = (t == 'u' || t == 'd') ? ub : (t == 's' ? lb : INFINITY);
+    };
+    for (int i = 0; i < m; i++) bnd(pb.rtype[i], pb.rlb ? pb.rlb[i] : 0, pb.rub ? pb.rub[i] : 0, &lo[i], &up[i]);
+    for (int k = 0; k < q; k++) lo[m + k] = up[m + k] = 0.0;
+    for (int j = 0; j < n; j++) bnd(pb.ctype[j], pb.clb ? pb.clb[j] : 0, pb.cub ? pb.cub[j] : 0, &lo[M + j], &up[M + j]);
+    for (int k = 0; k < q; k++) { lo[M + n + k] = -INFINITY; up[M + n + k] = INFINITY; }
+    bslv_lpq *lp = nullptr;
+    bslv_poly *poly = nullptr;
+    int rc = bslv_lpq_create(&lp, M, N, L.data(), lo.data(), up.data(), cost.data(), 0, 0, batch + 2);
+    if (rc) return rc;
+    auto done = [&](int r) { if (lp) bslv_lpq_destroy(lp); if (poly && r) { bslv_poly_destroy(poly); poly = nullptr; } return r; };
+    if ((rc = bslv_poly_create(&poly, q, 2 /* upperV2lowerH */, S.c.data()))) return done(rc);
+    const int zero = 0;
+    int st, it;
+    // a primal feasible basis first (zero objective: every basis is dual feasible, the dual simplex repairs the bounds) ...
+    if ((rc = bslv_lpq_reset_slot(lp, 0))) return done(rc);
+    if ((rc = bslv_lpq_solve_batch(lp, 1, &zero, &zero, nullptr, nullptr, &st, &it))) return done(rc);
+    if (st == BSLV_LP_INFEASIBLE) { *status = 1; bslv_poly_destroy(poly); poly = nullptr; return done(0); }
+    if (st != BSLV_LP_OPTIMAL) { set_error("phase 2 (dual): the feasibility LP has status %d", st); return done(BSLV_E_STATE); }
+    // ... then PART 1 (:1397-1443): w = mean of the columns of R
+    std::vector<double> w(q, 0.0), y(q), val(q);
+    for (int i = 0; i < q; i++) { for (int j = 0; j < S.r; j++) w[i] += S.R[(size_t)i * S.r + j]; w[i] /= S.r; }
+    if ((rc = bslv_lpq_solve_batch_obj(lp, 1, &zero, &zero, nullptr, nullptr, M + n, q, w.data(), &st, &it))) return done(rc);
+    if (st != BSLV_LP_OPTIMAL) { *status = st == BSLV_LP_INFEASIBLE ? 1 : 2; bslv_poly_destroy(poly); poly = nullptr; return done(0); }
+    ++*lps;
+    if ((rc = bslv_lpq_get_primal(lp, 1, &zero, M + n, q, y.data()))) return done(rc);
+    int prc;
+    if ((rc = bslv_poly_add(poly, y.data(), 0, &prc))) return done(rc);
+    for (int j = 0; j < S.h; j++) {                                                  // the recession cone's generators as directions
+        for (int i = 0; i < q; i++) val[i] = S.H[(size_t)i * S.h + j];
+        if ((rc = bslv_poly_add(poly, val.data(), 1, &prc))) return done(rc);
+    }
+    int irc = 0;
+    if ((rc = bslv_poly_init(poly, &irc))) return done(rc);
+    if (irc) { set_error("phase 2 (dual): initial outer approximation failed (bslv_poly.c:174)"); return done(BSLV_E_STATE); }
+    // PART 2 (:1445-1500), batched
+    std::vector<int> idx(batch), ideal(batch), parent(batch), src(batch, 0), dst(batch), stv(batch), itv(batch), rcv(batch), marks;
+    std::vector<double> vals((size_t)batch * q), W((size_t)batch * q), Y((size_t)batch * q), obj(batch), cuts;
+    for (int k = 0; k < batch; k++) dst[k] = k + 1;
+    for (;;) {
+        int cnt = 0;
+        if ((rc = bslv_poly_unprocessed2(poly, batch, 0, idx.data(), vals.data(), ideal.data(), parent.data(), &cnt))) return done(rc);
+        const int nb = std::min(cnt, batch);
+        if (nb == 0) break;
+        ++*steps;
+        marks.clear();
+        std::vector<int> pts;                                                        // positions of the points of this batch
+        for (int k = 0; k < nb; k++) { if (ideal[k]) marks.push_back(idx[k]); else pts.push_back(k); }   // :1456-1459
+        const int np = (int)pts.size();
+        for (int t = 0; t < np; t++) {                                               // w(y*) (:1461-1467)
+            const double *v = &vals[(size_t)pts[t] * q];
+            double last = 1.0;
+            for (int i = 0; i < q - 1; i++) { W[(size_t)t * q + i] = v[i]; last -= v[i] * S.c[i]; }
+            W[(size_t)t * q + q - 1] = last;
+        }
+        if (np > 0) {
+            if ((rc = bslv_lpq_solve_batch_obj(lp, np, src.data(), dst.data(), nullptr, nullptr, M + n, q, W.data(), stv.data(), itv.data()))) return done(rc);
+            for (int t = 0; t < np; t++) if (stv[t] != BSLV_LP_OPTIMAL) {
+                if (stv[t] == BSLV_LP_UNBOUNDED) { *status = 2; bslv_poly_destroy(poly); poly = nullptr; return done(0); }      // :1472-1477
+                set_error("phase 2 (dual): LP status %d (the reference asserts unboundedness here, bslv_algs.c:1474)", stv[t]);
+                return done(BSLV_E_STATE);
+            }
+            *lps += np;
+            if ((rc = bslv_lpq_get_primal(lp, np, dst.data(), M + n, q, Y.data()))) return done(rc);
+            if ((rc = bslv_lpq_get_obj(lp, np, dst.data(), obj.data()))) return done(rc);
+            cuts.clear();
+            std::vector<int> cut_src;
+            for (int t = 0; t < np; t++) {
+                const double opt_val = vals[(size_t)pts[t] * q + q - 1];
+                if (opt_val - obj[t] > eps) { cuts.insert(cuts.end(), &Y[(size_t)t * q], &Y[(size_t)t * q] + q); cut_src.push_back(idx[pts[t]]); }   // :1479-1486
+                else marks.push_back(idx[pts[t]]);                                                                                    // :1488-1497
+            }
+            const int nc = (int)cut_src.size();
+            if (nc > 0) {
+                if ((rc = bslv_poly_add_cuts(poly, nc, cuts.data(), nullptr, rcv.data()))) return done(rc);
+                for (int k = 0; k < nc; k++) if (rcv[k]) marks.push_back(cut_src[k]);      // nothing was cut off: the vertex stays, processed
+            }
+        }
+        if (!marks.empty() && (rc = bslv_poly_mark(poly, (int)marks.size(), marks.data()))) return done(rc);
+    }
+    *poly_out = poly;
+    return done(0);
+}
+
 }  // namespace bslv
 
 using namespace bslv;
@@ -308,6 +410,49 @@ int bslv_cone_vertenum(const double *gen, int n_in, int dim, double **prim, int 
     return 0;
 }
 
+// Shared front of the two entry points: sol_init, the sign normalisation, phases 0 and 1 (primal algorithm) unless bounded.
+// Returns with *vlp_status != 0 when the run ends here (input error, totally unbounded, no vertex).
+static int front(int m, int n, int q, const double *A, const double *P, const char *rtype, const double *rlb, const double *rub,
+                 const char *ctype, const double *clb, const double *cub, int optdir, int cone_kind, const double *gen, int n_gen,
+                 const double *c_in, int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, int batch,
+                 Sol &S, std::vector<double> &Pn, long *lps, long *steps, int *vlp_status, bslv_vlp_info *info)
+{
+    *vlp_status = 0;
+    if (info) memset(info, 0, sizeof *info);
+    char msg[200] = "";
+    int rc, st = 0;
+    if ((rc = sol_init(S, q, cone_kind, gen, n_gen, c_in, optdir, &st, msg, sizeof msg))) return rc;
+    if (st) { *vlp_status = st; if (info) snprintf(info->message, sizeof info->message, "%s", msg); return 0; }
+    if (info) { info->q = q; info->c_dir = S.c_dir; info->c = dup_vec(S.c); }      // c as written to _c.sol: before the sign change
+    sol_normalise(S, optdir);
+    Pn.assign(P, P + (size_t)q * n);
+    if (S.negate_P) for (double &v : Pn) v = -v;
+    Problem pb{m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub};
+    if (bounded) { S.R = S.Z; S.r = S.p; S.H = S.Y; S.h = S.o; }                     // phase2_init (bslv_algs.c:943-956)
+    else {
+        if ((rc = phase0(pb, S, eps_phase0, &st, lps))) return rc;
+        if (st) { *vlp_status = st; if (info) { info->lps = *lps; snprintf(info->message, sizeof info->message, "%s", st == 2 ? "VLP is totally unbounded, there is no solution" : "upper image of VLP has no vertex (this case is not covered by this version)"); } return 0; }
+        if ((rc = phase1_primal(pb, S, eps_phase1, eps_benson_phase1, batch, lps, steps))) return rc;
+    }
+    return 0;
+}
+static void fill_info(bslv_vlp_info *info, const Sol &S, int optdir, long lps, long steps)
+{
+    if (!info) return;
+    info->lps = lps; info->steps = steps;
+    info->o = S.o; info->p = S.p; info->r = S.r; info->h = S.h;
+    info->eta = dup_vec(S.eta); info->R = dup_vec(S.R); info->H = dup_vec(S.H); info->Y = dup_vec(S.Y); info->Z = dup_vec(S.Z);
+    // poly_trans_primal / poly_trans_dual (bslv_algs.c:221-240): what the writers have to undo
+    info->negate_primal = (S.c_dir > 0 && optdir == -1) || (S.c_dir < 0 && optdir == 1);
+    info->negate_dual_last = (optdir == -1);
+}
+static void phase2_failure(bslv_vlp_info *info, int vst, int bounded, long lps)
+{
+    if (!info) return;
+    info->lps = lps;                                                                 // bslv_main.c:311-329
+    snprintf(info->message, sizeof info->message, "%s", vst == 1 ? "VLP is infeasible" : bounded ? "VLP is not bounded, re-run without option -b" : "LP in phase 2 is not bounded, probably by inaccuracy in phase 1");
+}
+
 // The whole primal algorithm, bslv_main.c:236-345 without the file I/O.  P as written in the file (not negated).
 // On success with *vlp_status == 4 (VLP_OPTIMAL) *engine_out holds the finished phase-2 engine (its polyhedron is the
 // result; the caller destroys it) and info (may be NULL) the ordering-cone data.
@@ -323,47 +468,61 @@ int bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P,
         return BSLV_E_ARG;
     }
     *engine_out = nullptr;
-    *vlp_status = 0;
-    if (info) memset(info, 0, sizeof *info);
     Sol S;
-    char msg[200] = "";
-    int rc, st = 0;
-    if ((rc = sol_init(S, q, cone_kind, gen, n_gen, c_in, optdir, &st, msg, sizeof msg))) return rc;
-    if (st) { *vlp_status = st; if (info) snprintf(info->message, sizeof info->message, "%s", msg); return 0; }
-    if (info) { info->q = q; info->c_dir = S.c_dir; info->c = dup_vec(S.c); }      // c as written to _c.sol: before the sign change
-    sol_normalise(S, optdir);
-    std::vector<double> Pn(P, P + (size_t)q * n);
-    if (S.negate_P) for (double &v : Pn) v = -v;
-    Problem pb{m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub};
+    std::vector<double> Pn;
     long lps = 0, steps = 0;
-    if (bounded) { S.R = S.Z; S.r = S.p; S.H = S.Y; S.h = S.o; }                     // phase2_init (bslv_algs.c:943-956)
-    else {
-        if ((rc = phase0(pb, S, eps_phase0, &st, &lps))) return rc;
-        if (st) { *vlp_status = st; if (info) { info->lps = lps; snprintf(info->message, sizeof info->message, "%s", st == 2 ? "VLP is totally unbounded, there is no solution" : "upper image of VLP has no vertex (this case is not covered by this version)"); } return 0; }
-        if ((rc = phase1_primal(pb, S, eps_phase1, eps_benson_phase1, batch, &lps, &steps))) return rc;
-    }
+    int rc;
+    if ((rc = front(m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, optdir, cone_kind, gen, n_gen, c_in, bounded, eps_phase0, eps_phase1,
+                    eps_benson_phase1, batch, S, Pn, &lps, &steps, vlp_status, info))) return rc;
+    if (*vlp_status) return 0;
     bslv_benson *h = nullptr;
     if ((rc = bslv_benson_create_ex(&h, m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub, S.R.data(), S.r, S.c.data(), S.eta.data(), 0,
                                     eps_benson_phase2, std::max(4 * batch + 64, 64)))) return rc;
     int vst = 0;
     if ((rc = bslv_benson_start(h, &vst))) { bslv_benson_destroy(h); return rc; }
-    if (vst) {                                                                       // bslv_main.c:311-329
+    if (vst) {
         bslv_benson_destroy(h);
         *vlp_status = vst;                                                           // 1 VLP_INFEASIBLE, 2 VLP_UNBOUNDED
-        if (info) { info->lps = lps; snprintf(info->message, sizeof info->message, "%s", vst == 1 ? "VLP is infeasible" : bounded ? "VLP is not bounded, re-run without option -b" : "LP in phase 2 is not bounded, probably by inaccuracy in phase 1"); }
+        phase2_failure(info, vst, bounded, lps);
         return 0;
     }
     if ((rc = run_engine(h, batch, &lps, &steps))) { bslv_benson_destroy(h); return rc; }
     *engine_out = h;
     *vlp_status = 4;
-    if (info) {
-        info->lps = lps; info->steps = steps;
-        info->o = S.o; info->p = S.p; info->r = S.r; info->h = S.h;
-        info->eta = dup_vec(S.eta); info->R = dup_vec(S.R); info->H = dup_vec(S.H); info->Y = dup_vec(S.Y); info->Z = dup_vec(S.Z);
-        // poly_trans_primal (bslv_algs.c:221-229): what the writers have to undo
-        info->negate_primal = (S.c_dir > 0 && optdir == -1) || (S.c_dir < 0 && optdir == 1);
-        info->negate_dual_last = (optdir == -1);
+    fill_info(info, S, optdir, lps, steps);
+    return 0;
+}
+
+// The same with the DUAL algorithm in phase 2 ("-a dual": phase2_dual, bslv_algs.c:1381-1592; phases 0 and 1 stay primal, the
+// reference's default).  With status 4 *lower_image_out is a polyhedron whose PRIMAL side is the lower image and whose dual
+// side is the upper image (write it with bslv_sol_write3(..., swap = 1, ...)); destroy it with bslv_poly_destroy.
+int bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
+                         const char *rtype, const double *rlb, const double *rub,
+                         const char *ctype, const double *clb, const double *cub,
+                         int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
+                         int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
+                         int batch, bslv_poly **lower_image_out, int *vlp_status, bslv_vlp_info *info)
+{
+    if (!lower_image_out || !vlp_status || m < 1 || n < 1 || q < 2 || !A || !P || !rtype || !ctype || batch < 1 || (cone_kind != 0 && (!gen || n_gen < 1))) {
+        set_error("bslv_vlp_solve_dual2: bad argument");
+        return BSLV_E_ARG;
     }
+    *lower_image_out = nullptr;
+    Sol S;
+    std::vector<double> Pn;
+    long lps = 0, steps = 0;
+    int rc;
+    if ((rc = front(m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, optdir, cone_kind, gen, n_gen, c_in, bounded, eps_phase0, eps_phase1,
+                    eps_benson_phase1, batch, S, Pn, &lps, &steps, vlp_status, info))) return rc;
+    if (*vlp_status) return 0;
+    Problem pb{m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub};
+    int vst = 0;
+    bslv_poly *poly = nullptr;
+    if ((rc = phase2_dual(pb, S, eps_benson_phase2, batch, &poly, &vst, &lps, &steps))) return rc;
+    if (vst) { *vlp_status = vst; phase2_failure(info, vst, bounded, lps); return 0; }
+    *lower_image_out = poly;
+    *vlp_status = 4;
+    fill_info(info, S, optdir, lps, steps);
     return 0;
 }
 

@@ -230,6 +230,15 @@ int  bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P
                            int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
                            int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
                            int batch, bslv_benson **engine_out, int *vlp_status, bslv_vlp_info *info /* may be NULL */);
+/* the same with the DUAL algorithm in phase 2 ("-a dual": phase2_dual, bslv_algs.c:1381-1592, P1(w) LPs that differ in the
+ * objective; phases 0 and 1 stay primal).  With status 4 *lower_image_out is a polyhedron whose primal side is the LOWER image
+ * and whose dual side is the upper image: write it with bslv_sol_write3(..., swap = 1, ...), destroy with bslv_poly_destroy. */
+int  bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
+                          const char *rtype, const double *rlb, const double *rub,
+                          const char *ctype, const double *clb, const double *cub,
+                          int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
+                          int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
+                          int batch, bslv_poly **lower_image_out, int *vlp_status, bslv_vlp_info *info /* may be NULL */);
 void bslv_vlp_info_free(bslv_vlp_info *info);
 /* cone_vertenum: prim = the non-redundant generators among gen (dim x n_prim), dual = generators of the dual cone
  * (dim x n_dual); malloc'ed, free with bslv_free.  rc_out 1: the cone has no interior (poly__intl_apprx failed). */
@@ -248,6 +257,8 @@ const char *bslv_vlp_message(const struct bslv_vlp *v);
 int  bslv_sol_write(bslv_poly *poly, const char *base, const char *suffix, int optdir, long *counts /* 4, may be NULL */);
 /* the same with the two sign changes of poly_trans_primal (bslv_algs.c:221-229) spelled out (bslv_vlp_info) */
 int  bslv_sol_write2(bslv_poly *poly, const char *base, const char *suffix, int negate_primal, int negate_dual_last, long *counts);
+/* swap != 0: the engine's primal side is the LOWER image (dual algorithm; poly_output(..., SWAP, ...), bslv_algs.c:1566-1573) */
+int  bslv_sol_write3(bslv_poly *poly, const char *base, const char *suffix, int swap, int negate_upper, int negate_lower_last, long *counts);
 
 #ifdef __cplusplus
 }
