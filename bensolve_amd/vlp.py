@@ -37,9 +37,11 @@ def cone_vertenum(gen):
 
 
 def solve_primal(prob, cone_kind=0, gen=None, c=None, bounded=False, eps_phase0=1e-8, eps_phase1=1e-8, eps_benson_phase1=1e-7,
-                 eps_benson_phase2=1e-7, batch=256):
+                 eps_benson_phase2=1e-7, batch=256, alg_phase2="primal"):
     """prob: dict as bensolve_amd.synth builds them (P as in the file: not negated).  Returns dict(status, message, info...,
-    dump = slot-indexed dump of the result polyhedron with the sign changes of poly_trans_primal applied) ."""
+    dump = slot-indexed dump of the result polyhedron with the sign changes of poly_trans_primal applied).  alg_phase2 = "dual":
+    phase2_dual; the dump is then given with the sides swapped back, so that X / pi are the upper image in both cases."""
+    dual2 = alg_phase2 == "dual"
     lib = load_library()
     vp = ctypes.c_void_p
     A = np.ascontiguousarray(prob["A"], np.float64); P = np.ascontiguousarray(prob["P"], np.float64)
@@ -53,7 +55,8 @@ def solve_primal(prob, cone_kind=0, gen=None, c=None, bounded=False, eps_phase0=
     lib.bslv_vlp_solve_primal.argtypes = [ctypes.c_int] * 3 + [vp] * 8 + [ctypes.c_int] * 2 + [vp, ctypes.c_int, vp, ctypes.c_int] + [ctypes.c_double] * 4 + [ctypes.c_int, vp, vp, vp]
     lib.bslv_vlp_info_free.argtypes = [vp]
     lib.bslv_vlp_info_free.restype = None
-    check(lib.bslv_vlp_solve_primal(prob["m"], prob["n"], prob["q"], A.ctypes.data, P.ctypes.data, rt.ctypes.data, arrs[0].ctypes.data, arrs[1].ctypes.data,
+    lib.bslv_vlp_solve_dual2.argtypes = lib.bslv_vlp_solve_primal.argtypes
+    check((lib.bslv_vlp_solve_dual2 if dual2 else lib.bslv_vlp_solve_primal)(prob["m"], prob["n"], prob["q"], A.ctypes.data, P.ctypes.data, rt.ctypes.data, arrs[0].ctypes.data, arrs[1].ctypes.data,
                                     ct.ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, int(prob.get("optdir", 1)), cone_kind,
                                     None if g is None else g.ctypes.data, 0 if g is None else g.shape[1], None if cc is None else cc.ctypes.data,
                                     int(bounded), eps_phase0, eps_phase1, eps_benson_phase1, eps_benson_phase2, batch,
@@ -69,10 +72,13 @@ def solve_primal(prob, cone_kind=0, gen=None, c=None, bounded=False, eps_phase0=
         lib.bslv_benson_poly.argtypes = [vp]
         _bind_poly(lib)
         pe = PolyEngine.__new__(PolyEngine)
-        pe.lib, pe.h, pe.d = lib, vp(lib.bslv_benson_poly(h)), q
+        pe.lib, pe.h, pe.d = lib, (h if dual2 else vp(lib.bslv_benson_poly(h))), q
         pe.dual_adjacency()
         d = pe.dump()
-        pe.h = None                       # (the engine owns the polyhedron)
+        pe.h = None                       # (destroyed below)
+        if dual2:                         # primal side = lower image: swap the sides of the dump
+            d = dict(d=q, pu=d["du"], pi=d["di"], ps=np.zeros_like(d["du"]), X=d["Y"], du=d["pu"], di=d["pi"], Y=d["X"],
+                     E=d["DE"], DE=d["E"], I=d["I"][:, ::-1].copy())
         if info.negate_primal:
             d["X"] = -d["X"]
         if info.negate_dual_last:
@@ -80,6 +86,8 @@ def solve_primal(prob, cone_kind=0, gen=None, c=None, bounded=False, eps_phase0=
         out["dump"] = d
         lib.bslv_benson_destroy.argtypes = [vp]
         lib.bslv_benson_destroy.restype = None
-        lib.bslv_benson_destroy(h)
+        lib.bslv_poly_destroy.argtypes = [vp]
+        lib.bslv_poly_destroy.restype = None
+        (lib.bslv_poly_destroy if dual2 else lib.bslv_benson_destroy)(h)
     lib.bslv_vlp_info_free(ctypes.byref(info))
     return out
