@@ -2039,8 +2039,9 @@ static int grow(T **p, size_t oldn, size_t newn, hipStream_t s, bool zero_tail =
 
 static int ensure_vcap(bslv_poly *h, int need)
 {
+    if (need < 0 || need > 0x7FFFFF00 / 2) { set_error("polyhedron too large: more than 2^30 elements"); return BSLV_E_CAPACITY; }
     if (need <= h->P.cap) return 0;
-    int ncap = std::max(need, std::max(1024, h->P.cap * 2));
+    int ncap = (int)std::min<long long>(std::max<long long>(need, std::max<long long>(1024, 2ll * h->P.cap)), 0x7FFFFF00 / 2);
     PolyView &P = h->P;
     // SoA coordinates: re-stride
     double *X = nullptr;
@@ -2079,8 +2080,10 @@ static int ensure_pool(bslv_poly *h, size_t need)
 }
 static int ensure_ecap(bslv_poly *h, int need)
 {
+    // edge, element and pool indices are 32-bit: refuse instead of wrapping around (a 10-dimensional degenerate image gets there)
+    if (need < 0 || need > 0x7FFFFF00 / 2) { set_error("polyhedron too large: more than 2^30 edges"); return BSLV_E_CAPACITY; }
     if (need <= h->ecap) return 0;
-    int ncap = std::max(need, std::max(4096, h->ecap * 2));
+    int ncap = (int)std::min<long long>(std::max<long long>(need, std::max<long long>(4096, 2ll * h->ecap)), 0x7FFFFF00 / 2);
     int rc;
     if ((rc = grow(&h->E[h->ecur], h->ne, ncap, h->stream))) return rc;
     if ((rc = grow(&h->E[1 - h->ecur], 0, ncap, h->stream))) return rc;
@@ -2192,6 +2195,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     if ((rc = wait_mail(h, 2, seq))) return rc;
     const Tri tp = h->mail_h[2].t;
     if (tp.a > 0) {
+        if ((long long)h->ne + tp.a > 0x3FFFFF00ll) { set_error("polyhedron too large: more than 2^30 edges"); return BSLV_E_CAPACITY; }
         if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
         hipLaunchKernelGGL(k_pair_emit, dim3((unsigned)nbp), dim3(PB), 0, s, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum,
                            h->E[h->ecur], h->ne, h->EP[h->ecur]);
