@@ -17,6 +17,7 @@ static void usage(void)
 {
     printf("Usage: bensolve_hip file.vlp [options]\n"
            "  -b, --bounded            assume the problem is bounded: skip phases 0 and 1 (R := Z)\n"
+           "  -A, --alg_phase1 ALG     primal (default) or dual: the algorithm of phase 1\n"
            "  -a, --alg_phase2 ALG     primal (default) or dual: Benson's algorithm or its dual variant in phase 2\n"
            "  -E, --eps_phase1 EPS     epsilon of Benson's algorithm in phase 1 (default 1e-7)\n"
            "  -e, --eps_phase2 EPS     epsilon of Benson's algorithm in phase 2 (default 1e-7)\n"
@@ -44,6 +45,10 @@ int main(int argc, char **argv)
         else if (!strcmp(o, "-a") || !strcmp(o, "--alg_phase2")) {
             const char *v2 = ARG();
             if (!strcmp(v2, "dual")) dual2 = 1; else if (!strcmp(v2, "primal")) dual2 = 0; else { printf("option --alg_phase2 (-a): invalid argument\n"); return 1; }
+        }
+        else if (!strcmp(o, "-A") || !strcmp(o, "--alg_phase1")) {
+            const char *v1 = ARG();
+            if (!strcmp(v1, "dual")) bslv_vlp_set_alg_phase1(1); else if (!strcmp(v1, "primal")) bslv_vlp_set_alg_phase1(0); else { printf("option --alg_phase1 (-A): invalid argument\n"); return 1; }
         }
         else if (!strcmp(o, "-E") || !strcmp(o, "--eps_phase1")) { eps1 = atof(ARG()); if (!(eps1 > 0)) { printf("option --eps_phase1 (-E): invalid argument\n"); return 1; } }
         else if (!strcmp(o, "-h") || !strcmp(o, "--help")) { usage(); return 1; }

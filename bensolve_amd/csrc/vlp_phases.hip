@@ -286,22 +286,28 @@ static int phase1_primal(const Problem &pb, Sol &S, double eps_phase1, double ep
 //      (init_P1, :1186-1238); its optimal y cuts y* off when y*_q - w.y > eps.  The LPs of a batch differ only in the
 //      objective: bslv_lpq_solve_batch_obj, all warm-started from the first solved basis (slot 0).
 //      status: 0 ok, 1 VLP_INFEASIBLE, 2 VLP_UNBOUNDED.  The polyhedron (primal side = lower image) is handed to the caller. ----
-static int phase2_dual(const Problem &pb, const Sol &S, double eps, int batch, bslv_poly **poly_out, int *status, long *lps, long *steps)
+//      hom != 0: the homogeneous problem of phase1_dual (:1248-1371; init_P1(..., HOMOGENEOUS): bounds zeroed, one more row
+//      eta.y <= 1), started with the mean of the columns of Z and the generators Y of the ordering cone as directions.
+static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int batch, bslv_poly **poly_out, int *status, long *lps, long *steps)
 {
     *status = 0; *poly_out = nullptr;
-    const int m = pb.m, n = pb.n, q = pb.q, M = m + q, N = n + q;
+    const int m = pb.m, n = pb.n, q = pb.q, M = m + q + (hom ? 1 : 0), N = n + q;
+    const std::vector<double> &W0 = hom ? S.Z : S.R, &D0 = hom ? S.Y : S.H;
+    const int nw0 = hom ? S.p : S.r, nd0 = hom ? S.o : S.h;
     std::vector<double> L((size_t)M * N, 0.0), lo(M + N), up(M + N), cost(N + 1, 0.0);
     for (int i = 0; i < m; i++) memcpy(&L[(size_t)i * N], pb.A + (size_t)i * n, n * sizeof(double));
     for (int k = 0; k < q; k++) {
         for (int j = 0; j < n; j++) L[(size_t)(m + k) * N + j] = -pb.P[(size_t)k * n + j];
         L[(size_t)(m + k) * N + n + k] = 1.0;
     }
-    auto bnd = [](char t, double lb, double ub, double *l, double *u) {
+    auto bnd = [hom](char t, double lb, double ub, double *l, double *u) {
+        if (hom) { lb = ub = 0.0; if (t == 'd') t = 's'; }                           // lp_set_rows_hom / lp_set_cols_hom (bslv_lp.c:118-134)
         *l = (t == 'l' || t == 'd' || t == 's') ? lb : -INFINITY;
         *u = (t == 'u' || t == 'd') ? ub : (t == 's' ? lb : INFINITY);
     };
     for (int i = 0; i < m; i++) bnd(pb.rtype[i], pb.rlb ? pb.rlb[i] : 0, pb.rub ? pb.rub[i] : 0, &lo[i], &up[i]);
     for (int k = 0; k < q; k++) lo[m + k] = up[m + k] = 0.0;
+    if (hom) { for (int k = 0; k < q; k++) L[(size_t)(m + q) * N + n + k] = S.eta[k]; lo[m + q] = -INFINITY; up[m + q] = 1.0; }   // :1201-1226
     for (int j = 0; j < n; j++) bnd(pb.ctype[j], pb.clb ? pb.clb[j] : 0, pb.cub ? pb.cub[j] : 0, &lo[M + j], &up[M + j]);
     for (int k = 0; k < q; k++) { lo[M + n + k] = -INFINITY; up[M + n + k] = INFINITY; }
     bslv_lpq *lp = nullptr;
@@ -319,15 +325,15 @@ static int phase2_dual(const Problem &pb, const Sol &S, double eps, int batch, b
     if (st != BSLV_LP_OPTIMAL) { set_error("phase 2 (dual): the feasibility LP has status %d", st); return done(BSLV_E_STATE); }
     // ... then PART 1 (:1397-1443): w = mean of the columns of R
     std::vector<double> w(q, 0.0), y(q), val(q);
-    for (int i = 0; i < q; i++) { for (int j = 0; j < S.r; j++) w[i] += S.R[(size_t)i * S.r + j]; w[i] /= S.r; }
+    for (int i = 0; i < q; i++) { for (int j = 0; j < nw0; j++) w[i] += W0[(size_t)i * nw0 + j]; w[i] /= nw0; }
     if ((rc = bslv_lpq_solve_batch_obj(lp, 1, &zero, &zero, nullptr, nullptr, M + n, q, w.data(), &st, &it))) return done(rc);
     if (st != BSLV_LP_OPTIMAL) { *status = st == BSLV_LP_INFEASIBLE ? 1 : 2; bslv_poly_destroy(poly); poly = nullptr; return done(0); }
     ++*lps;
     if ((rc = bslv_lpq_get_primal(lp, 1, &zero, M + n, q, y.data()))) return done(rc);
     int prc;
     if ((rc = bslv_poly_add(poly, y.data(), 0, &prc))) return done(rc);
-    for (int j = 0; j < S.h; j++) {                                                  // the recession cone's generators as directions
-        for (int i = 0; i < q; i++) val[i] = S.H[(size_t)i * S.h + j];
+    for (int j = 0; j < nd0; j++) {                                                  // the (recession | ordering) cone's generators as directions
+        for (int i = 0; i < q; i++) val[i] = D0[(size_t)i * nd0 + j];
         if ((rc = bslv_poly_add(poly, val.data(), 1, &prc))) return done(rc);
     }
     int irc = 0;
@@ -382,6 +388,41 @@ static int phase2_dual(const Problem &pb, const Sol &S, double eps, int batch, b
     return done(0);
 }
 
+static int phase2_dual(const Problem &pb, const Sol &S, double eps, int batch, bslv_poly **poly_out, int *status, long *lps, long *steps)
+{
+    return dual_benson(pb, S, 0, eps, batch, poly_out, status, lps, steps);
+}
+
+// ---- phase 1, dual algorithm (bslv_algs.c:1248-1371): the dual variant on the homogeneous problem; R from the vertices of
+//      the lower image with last component 0 (now on the PRIMAL side of the polyhedron), H their dual cone. ----
+static int phase1_dual(const Problem &pb, Sol &S, double eps_phase1, double eps_benson, int batch, long *lps, long *steps)
+{
+    const int q = pb.q;
+    bslv_poly *poly = nullptr;
+    int st = 0;
+    int rc = dual_benson(pb, S, 1, eps_benson, batch, &poly, &st, lps, steps);
+    if (rc) return rc;
+    if (st || !poly) { set_error("phase 1 (dual): an LP of the homogeneous problem is not optimal (the reference asserts, bslv_algs.c:1282)"); return BSLV_E_STATE; }
+    auto done = [&](int r) { bslv_poly_destroy(poly); return r; };
+    const int np = bslv_poly_nprimal(poly);
+    std::vector<unsigned char> pu(np), pi(np), ps(np);
+    std::vector<double> pc((size_t)np * q);
+    if ((rc = bslv_poly_get_primal(poly, pu.data(), pi.data(), ps.data(), pc.data()))) return done(rc);
+    std::vector<int> sel;
+    for (int l = 0; l < np; l++) if (pu[l] && !pi[l] && fabs(pc[(size_t)l * q + q - 1]) < eps_phase1) sel.push_back(l);     // :1344-1357
+    const int pp = (int)sel.size();
+    std::vector<double> arr((size_t)q * pp);
+    for (int i = 0; i < pp; i++) {
+        double last = 1.0;
+        for (int j = 0; j < q - 1; j++) { const double v = pc[(size_t)sel[i] * q + j]; arr[(size_t)j * pp + i] = v; last -= S.c[j] * v; }
+        arr[(size_t)(q - 1) * pp + i] = last;
+    }
+    int fail = 0;
+    if ((rc = cone_vertenum(arr.data(), pp, q, S.R, S.r, S.H, S.h, fail))) return done(rc);
+    if (fail || S.r < 1) { set_error("phase 1 (dual): the recession cone data could not be enumerated (%d candidate generators)", pp); return done(BSLV_E_STATE); }
+    return done(0);
+}
+
 }  // namespace bslv
 
 using namespace bslv;
@@ -410,11 +451,15 @@ int bslv_cone_vertenum(const double *gen, int n_in, int dim, double **prim, int 
     return 0;
 }
 
+// "-A dual": phase 1 by the dual variant for the calls that follow (opt->alg_phase1, bslv_main.c:283-296); per thread
+static thread_local int g_alg_phase1_dual = 0;
+int bslv_vlp_set_alg_phase1(int dual) { g_alg_phase1_dual = dual != 0; return 0; }
+
 // Shared front of the two entry points: sol_init, the sign normalisation, phases 0 and 1 (primal algorithm) unless bounded.
 // Returns with *vlp_status != 0 when the run ends here (input error, totally unbounded, no vertex).
 static int front(int m, int n, int q, const double *A, const double *P, const char *rtype, const double *rlb, const double *rub,
                  const char *ctype, const double *clb, const double *cub, int optdir, int cone_kind, const double *gen, int n_gen,
-                 const double *c_in, int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, int batch,
+                 const double *c_in, int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, int batch, int dual1,
                  Sol &S, std::vector<double> &Pn, long *lps, long *steps, int *vlp_status, bslv_vlp_info *info)
 {
     *vlp_status = 0;
@@ -432,7 +477,8 @@ static int front(int m, int n, int q, const double *A, const double *P, const ch
     else {
         if ((rc = phase0(pb, S, eps_phase0, &st, lps))) return rc;
         if (st) { *vlp_status = st; if (info) { info->lps = *lps; snprintf(info->message, sizeof info->message, "%s", st == 2 ? "VLP is totally unbounded, there is no solution" : "upper image of VLP has no vertex (this case is not covered by this version)"); } return 0; }
-        if ((rc = phase1_primal(pb, S, eps_phase1, eps_benson_phase1, batch, lps, steps))) return rc;
+        if ((rc = dual1 ? phase1_dual(pb, S, eps_phase1, eps_benson_phase1, batch, lps, steps)
+                        : phase1_primal(pb, S, eps_phase1, eps_benson_phase1, batch, lps, steps))) return rc;
     }
     return 0;
 }
@@ -473,7 +519,7 @@ int bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P,
     long lps = 0, steps = 0;
     int rc;
     if ((rc = front(m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, optdir, cone_kind, gen, n_gen, c_in, bounded, eps_phase0, eps_phase1,
-                    eps_benson_phase1, batch, S, Pn, &lps, &steps, vlp_status, info))) return rc;
+                    eps_benson_phase1, batch, g_alg_phase1_dual, S, Pn, &lps, &steps, vlp_status, info))) return rc;
     if (*vlp_status) return 0;
     bslv_benson *h = nullptr;
     if ((rc = bslv_benson_create_ex(&h, m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub, S.R.data(), S.r, S.c.data(), S.eta.data(), 0,
@@ -513,7 +559,7 @@ int bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
     long lps = 0, steps = 0;
     int rc;
     if ((rc = front(m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, optdir, cone_kind, gen, n_gen, c_in, bounded, eps_phase0, eps_phase1,
-                    eps_benson_phase1, batch, S, Pn, &lps, &steps, vlp_status, info))) return rc;
+                    eps_benson_phase1, batch, g_alg_phase1_dual, S, Pn, &lps, &steps, vlp_status, info))) return rc;
     if (*vlp_status) return 0;
     Problem pb{m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub};
     int vst = 0;

@@ -239,6 +239,9 @@ int  bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
                           int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
                           int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
                           int batch, bslv_poly **lower_image_out, int *vlp_status, bslv_vlp_info *info /* may be NULL */);
+/* "-A dual" (opt->alg_phase1, bslv_main.c:283-296): phase 1 of the calls that follow on this thread runs the dual variant
+ * (phase1_dual, bslv_algs.c:1248-1371) instead of phase1_primal */
+int  bslv_vlp_set_alg_phase1(int dual);
 void bslv_vlp_info_free(bslv_vlp_info *info);
 /* cone_vertenum: prim = the non-redundant generators among gen (dim x n_prim), dual = generators of the dual cone
  * (dim x n_dual); malloc'ed, free with bslv_free.  rc_out 1: the cone has no interior (poly__intl_apprx failed). */

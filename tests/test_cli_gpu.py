@@ -85,15 +85,15 @@ def _gold_rows(t, X):
     return t[o], X[o]
 
 
-@pytest.mark.parametrize("alg", ["primal", "dual"])
+@pytest.mark.parametrize("alg1,alg", [("primal", "primal"), ("primal", "dual"), ("dual", "dual"), ("dual", "primal")])
 @pytest.mark.parametrize("ex", ["ex01", "ex05", "ex06", "ex08", "ex11"])
-def test_cli_all_phases_match_hybrid_goldens(tmp_path, ex, alg):
+def test_cli_all_phases_match_hybrid_goldens(tmp_path, ex, alg1, alg):
     """ex01: unbounded upper image (phases 0/1 find the recession cone); ex05 / ex08: ordering cone given by generators,
     ex06: by generators of its dual, a max problem; ex11: q = 5.  alg = dual: the dual variant of Benson's algorithm in
     phase 2 (phase2_dual: outer approximation of the lower image by P1(w) LPs that differ in the objective) must arrive at the
-    same pair of images."""
+    same pair of images; alg1 = dual: phase1_dual finds the recession cone data on the homogeneous problem the same way."""
     base = os.path.join(tmp_path, ex)
-    r = subprocess.run([CLI, os.path.join(EXDIR, ex + ".vlp"), "-m", "2", "-B", "64", "-a", alg, "-o", base], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([CLI, os.path.join(EXDIR, ex + ".vlp"), "-m", "2", "-B", "64", "-A", alg1, "-a", alg, "-o", base], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     for side in ("p", "d"):
         t, X, _ = read_img(base + "_img_%s.sol" % side)
