@@ -30,6 +30,11 @@ struct bslv_benson {
     int m = 0, n = 0, q = 0, r = 0, M = 0, N = 0;     // m: rows of A left after the presolve
     int rows_folded = 0;                              // singleton rows of A turned into column bounds
     bool hom = false;                                 // homogeneous problem (phases 0 and 1)
+    // option -s (opt->solution == PRE_IMG_ON): x of every confirmed vertex, (u, w) of every cut (bslv_algs.c:1064-1079)
+    bool want_primg = false;
+    int m_orig = 0;                                   // rows of A as given (pre-images need every row: no presolve)
+    std::unordered_map<int, std::vector<double>> primg_p, primg_d;      // by primal element / by facet (dual slot)
+    std::vector<std::pair<std::vector<double>, std::vector<double>>> start_primg;   // PART 1: (y*, (u, w)) until the slots exist
     std::vector<double> eta;                          // q: coefficients of the last row (eta.y <= 1 when hom)
     double eps = 1e-7;
     std::vector<double> R, c;           // q x r (generators as columns), q
@@ -90,7 +95,7 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
                        const char *ctype, const double *clb, const double *cub,
                        const double *R, int r, const double *c, double eps, int pool_slots)
 {
-    return bslv_benson_create_ex(out, m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, R, r, c, nullptr, 0, eps, pool_slots);
+    return bslv_benson_create_ex(out, m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, R, r, c, nullptr, 0, 0, eps, pool_slots);
 }
 
 // hom != 0: the HOMOGENEOUS problem of phases 0 and 1 (init_P2(..., HOMOGENEOUS), bslv_algs.c:574-664): every bound of the
@@ -99,7 +104,7 @@ int bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A, 
 int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *A, const double *P,
                           const char *rtype, const double *rlb, const double *rub,
                           const char *ctype, const double *clb, const double *cub,
-                          const double *R, int r, const double *c, const double *eta, int hom, double eps, int pool_slots)
+                          const double *R, int r, const double *c, const double *eta, int hom, int flags, double eps, int pool_slots)
 {
     if (!out || m < 1 || n < 1 || q < 2 || r < 1 || !A || !P || !rtype || !ctype || !R || !c || pool_slots < 4) {
         set_error("bslv_benson_create: bad argument");
@@ -122,7 +127,7 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
         for (int j = 0; j < n && nz < 2; j++) if (A[(size_t)i * n + j] != 0.0) { nz++; jj = j; }
         double lo_i, up_i;
         vlp_bounds(rtype[i], rlb ? rlb[i] : 0, rub ? rub[i] : 0, &lo_i, &up_i);
-        if (nz == 1 && !getenv("BSLV_NO_PRESOLVE")) {
+        if (nz == 1 && !(flags & BSLV_BENSON_PREIMAGES) && !getenv("BSLV_NO_PRESOLVE")) {
             const double a = A[(size_t)i * n + jj];
             double lo = a > 0 ? lo_i / a : up_i / a, up = a > 0 ? up_i / a : lo_i / a;
             lo = std::max(lo, clo[jj]); up = std::min(up, cup[jj]);
@@ -130,6 +135,8 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
         }
         keep.push_back(i);
     }
+    h->want_primg = (flags & BSLV_BENSON_PREIMAGES) != 0;
+    h->m_orig = m;
     h->rows_folded = m - (int)keep.size();
     if (keep.empty()) { keep.push_back(0); h->rows_folded = m - 1; }      // (the LP layer wants at least one row of A)
     m = (int)keep.size();
@@ -198,12 +205,32 @@ int bslv_benson_start(bslv_benson *h, int *vlp_status)
         if ((rc = bslv_lpq_get_obj(h->lp, 1, &zero, &obj))) return rc;
         for (int k = 0; k < q; k++) val[k] = h->R[(size_t)k * r + j];
         val[q - 1] = obj;
+        if (h->want_primg) {                                                         // (u, w) of the weighted-sum LP (:1001-1006)
+            std::vector<double> uw(h->m + q);
+            if ((rc = bslv_lpq_get_dual(h->lp, 1, &zero, 0, h->m + q, uw.data()))) return rc;
+            h->start_primg.emplace_back(val, uw);
+        }
         int prc;
         if ((rc = bslv_poly_add(h->poly, val.data(), 0, &prc))) return rc;
     }
     int irc;
     if ((rc = bslv_poly_init(h->poly, &irc))) return rc;
     if (irc) { set_error("initial outer approximation failed (rank-deficient start, bslv_poly.c:174)"); return BSLV_E_STATE; }
+    if (h->want_primg) {
+        // poly__intl_apprx re-adds the queued halfspaces as new dual slots (bslv_poly.c:190-197): find them by their coordinates
+        const int nd = bslv_poly_ndual(h->poly);
+        std::vector<unsigned char> du(nd), di(nd);
+        std::vector<double> dc((size_t)nd * q);
+        if ((rc = bslv_poly_get_dual(h->poly, du.data(), di.data(), dc.data()))) return rc;
+        for (int f = 0; f < nd; f++) {
+            if (!du[f] || di[f]) continue;
+            for (auto &sp : h->start_primg) {
+                double dd = 0;
+                for (int k = 0; k < q; k++) dd = std::max(dd, std::fabs(sp.first[k] - dc[(size_t)f * q + k]));
+                if (dd <= 1e-12 * (1.0 + std::fabs(sp.first[q - 1]))) { h->primg_d[f] = sp.second; break; }
+            }
+        }
+    }
     h->facet_owner.assign(bslv_poly_ndual(h->poly), -1);
     h->started = true;
     return 0;
@@ -433,6 +460,15 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     int rc;
     if (nfail) { set_error("%ld LP(s) of the batch did not reach optimality (the reference asserts here, bslv_algs.c:1049)", nfail); return BSLV_E_STATE; }
     if (!confirmed.empty() && (rc = bslv_poly_mark(h->poly, (int)confirmed.size(), confirmed.data()))) return rc;
+    if (h->want_primg && !confirmed.empty()) {                                       // x of the confirmed vertices (:1078)
+        std::unordered_map<int, int> slot_of;
+        for (size_t k = 0; k < B.l_pos.size(); k++) slot_of[B.b_idx[B.l_pos[k]]] = B.l_slot[k];
+        std::vector<int> ids, slots;
+        for (int v : confirmed) { auto it = slot_of.find(v); if (it != slot_of.end()) { ids.push_back(v); slots.push_back(it->second); } }
+        std::vector<double> X((size_t)ids.size() * h->n);
+        if (!ids.empty() && (rc = bslv_lpq_get_primal(h->lp, (int)ids.size(), slots.data(), h->M, h->n, X.data()))) return rc;
+        for (size_t k = 0; k < ids.size(); k++) h->primg_p[ids[k]].assign(X.begin() + k * h->n, X.begin() + (k + 1) * h->n);
+    }
     const int ncut = (int)cut_src.size();
     std::vector<int> prc(ncut, 0);
     const int f0 = bslv_poly_ndual(h->poly);
@@ -452,6 +488,12 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
         if (owner == h->rank) {
             auto it = slot_of_src.find((int)rec[0]);
             if (it != slot_of_src.end()) {
+                if (prc[c] == 0 && h->want_primg) {                                 // (u, w) of the cut (:1066-1071)
+                    std::vector<double> uw(h->m + q);
+                    const int sl = it->second;
+                    if ((rc = bslv_lpq_get_dual(h->lp, 1, &sl, 0, h->m + q, uw.data()))) return rc;
+                    h->primg_d[f] = uw;
+                }
                 if (prc[c] == 0) { h->facet_slot[f] = it->second; h->parents.emplace_back(f, it->second); }
                 else h->free_slots.push_back(it->second);
                 slot_of_src.erase(it);
@@ -498,6 +540,30 @@ int bslv_benson_set_policy(bslv_benson *h, int policy)
 {
     if (!h || policy < 1 || policy > 2) return BSLV_E_ARG;
     h->policy = policy;
+    return 0;
+}
+// pre-images (option -s): x[n] of a vertex of the upper image / (u[m], w[q]) of a vertex of the lower image.  Returns 0 and
+// fills out, or 1 when nothing was stored for that element (directions; elements that were never confirmed).
+int bslv_benson_preimage_p(const bslv_benson *h, int element, double *x)
+{
+    if (!h || !x) return BSLV_E_ARG;
+    auto it = h->primg_p.find(element);
+    if (it == h->primg_p.end()) return 1;
+    memcpy(x, it->second.data(), it->second.size() * sizeof(double));
+    return 0;
+}
+int bslv_benson_preimage_d(const bslv_benson *h, int facet, double *uw)
+{
+    if (!h || !uw) return BSLV_E_ARG;
+    auto it = h->primg_d.find(facet);
+    if (it == h->primg_d.end()) return 1;
+    memcpy(uw, it->second.data(), it->second.size() * sizeof(double));
+    return 0;
+}
+int bslv_benson_set_preimage_p(bslv_benson *h, int element, const double *x)
+{
+    if (!h || !x) return BSLV_E_ARG;
+    h->primg_p[element].assign(x, x + h->n);
     return 0;
 }
 int bslv_benson_lp_dims(const bslv_benson *h, int *M, int *N, int *rows_folded)

@@ -17,6 +17,7 @@ static void usage(void)
 {
     printf("Usage: bensolve_hip file.vlp [options]\n"
            "  -b, --bounded            assume the problem is bounded: skip phases 0 and 1 (R := Z)\n"
+           "  -s, --solution           write the solutions (pre-images) to <name>_pre_img_p.sol / _pre_img_d.sol (primal algorithm in phase 2)\n"
            "  -A, --alg_phase1 ALG     primal (default) or dual: the algorithm of phase 1\n"
            "  -a, --alg_phase2 ALG     primal (default) or dual: Benson's algorithm or its dual variant in phase 2\n"
            "  -E, --eps_phase1 EPS     epsilon of Benson's algorithm in phase 1 (default 1e-7)\n"
@@ -31,7 +32,7 @@ int main(int argc, char **argv)
 {
     if (argc < 2 || argv[1][0] == '-') { usage(); return 1; }
     const char *file = argv[1];
-    int bounded = 0, msg = 1, batch = 1024, dual2 = 0;
+    int bounded = 0, msg = 1, batch = 1024, dual2 = 0, dual1 = 0, presol = 0;
     double eps = 1e-7, eps1 = 1e-7;
     char base[1024] = "";
     for (int a = 2; a < argc; a++) {
@@ -46,9 +47,10 @@ int main(int argc, char **argv)
             const char *v2 = ARG();
             if (!strcmp(v2, "dual")) dual2 = 1; else if (!strcmp(v2, "primal")) dual2 = 0; else { printf("option --alg_phase2 (-a): invalid argument\n"); return 1; }
         }
+        else if (!strcmp(o, "-s") || !strcmp(o, "--solution")) { presol = 1; bslv_vlp_set_preimages(1); }
         else if (!strcmp(o, "-A") || !strcmp(o, "--alg_phase1")) {
             const char *v1 = ARG();
-            if (!strcmp(v1, "dual")) bslv_vlp_set_alg_phase1(1); else if (!strcmp(v1, "primal")) bslv_vlp_set_alg_phase1(0); else { printf("option --alg_phase1 (-A): invalid argument\n"); return 1; }
+            if (!strcmp(v1, "dual")) bslv_vlp_set_alg_phase1(dual1 = 1); else if (!strcmp(v1, "primal")) bslv_vlp_set_alg_phase1(dual1 = 0); else { printf("option --alg_phase1 (-A): invalid argument\n"); return 1; }
         }
         else if (!strcmp(o, "-E") || !strcmp(o, "--eps_phase1")) { eps1 = atof(ARG()); if (!(eps1 > 0)) { printf("option --eps_phase1 (-E): invalid argument\n"); return 1; } }
         else if (!strcmp(o, "-h") || !strcmp(o, "--help")) { usage(); return 1; }
@@ -91,7 +93,47 @@ int main(int argc, char **argv)
     double elapsed = now() - t0;
     long cnt[4], lps = 0, cuts = 0, piv = 0;
     if ((rc = bslv_sol_write3(dual2 ? lower : bslv_benson_poly(h), base, ".sol", dual2, info.negate_primal, info.negate_dual_last, cnt))) { printf("writing results failed (%d): %s\n", rc, bslv_last_error()); return 3; }
+    if (presol && h && (rc = bslv_sol_write_preimages(h, base, ".sol", v->m, v->n, v->optdir, info.c_dir))) { printf("writing the pre-images failed (%d): %s\n", rc, bslv_last_error()); return 3; }
+    if (presol && !h) printf("option -s is implemented for the primal algorithm in phase 2 only: no pre-image files\n");
     if (h) bslv_benson_totals(h, &lps, &cuts, &piv);
+    {   /* <name>.log, fields and layout of bslv_main.c:346-397 */
+        char lfile[1100];
+        snprintf(lfile, sizeof lfile, "%s.log", base);
+        FILE *lf = fopen(lfile, "w");
+        if (!lf) { printf("unable to open file %s", lfile); return 1; }
+        fprintf(lf, "BENSOLVE: VLP solver, bensolve_hip (MI355X engine behind the BENSOLVE 2.0.1 file formats)\n");
+        fprintf(lf, "Problem parameters\n");
+        fprintf(lf, "  problem file:      %s\n", lfile);
+        fprintf(lf, "  problem rows:      %7d\n", v->m);
+        fprintf(lf, "  problem columns:   %7d\n", v->n);
+        fprintf(lf, "  matrix non-zeros:  %7ld\n", v->nz);
+        fprintf(lf, "  primal generators: %7d\n", info.o);
+        fprintf(lf, "  dual generators:   %7d\n", info.p);
+        fprintf(lf, "Options\n");
+        fprintf(lf, "  bounded:            %s\n", bounded ? "yes (run phase 2 only)" : "no (run phases 0 to 2)");
+        fprintf(lf, "  solution:           %s\n", presol ? "on (solutions (pre-image) written to files)" : "off (no solution output)");
+        fprintf(lf, "  format:             %s\n", "long");
+        fprintf(lf, "  lp_method_phase0:   %s\n", "dual_primal_simplex (dual simplex, if not succesful, primal simplex)");
+        fprintf(lf, "  lp_method_phase1:   %s\n", "dual_primal_simplex (dual simplex, if not succesful, primal simplex)");
+        fprintf(lf, "  lp_method_phase2:   %s\n", dual2 ? "primal_simplex" : "dual_primal_simplex (dual simplex, if not succesful, primal simplex)");
+        fprintf(lf, "  message_level:      %d\n", msg);
+        fprintf(lf, "  lp_message_level:   %d\n", 0);
+        fprintf(lf, "  alg_phase1:         %s\n", dual1 ? "dual" : "primal");
+        fprintf(lf, "  alg_phase2:         %s\n", dual2 ? "dual" : "primal");
+        fprintf(lf, "  eps_benson_phase1:  %g\n", eps1);
+        fprintf(lf, "  eps_benson_phase2:  %g\n", eps);
+        fprintf(lf, "  eps_phase0:         %g\n", 1e-8);
+        fprintf(lf, "  eps_phase1:         %g\n", 1e-8);
+        fprintf(lf, "Computational results\n");
+        fprintf(lf, "  CPU time (ms):      %g\n", elapsed * 1e3);
+        fprintf(lf, "  # LPs:              %ld\n", info.lps);
+        fprintf(lf, "Solution properties\n");
+        fprintf(lf, "  # primal solution points:     %7ld\n", cnt[0]);
+        fprintf(lf, "  # primal solution directions: %7ld\n", cnt[1]);
+        fprintf(lf, "  # dual solution points:       %7ld\n", cnt[2]);
+        fprintf(lf, "  # dual solution directions:   %7ld\n", cnt[3]);
+        fclose(lf);
+    }
     if (msg >= 1) {
         printf("CPU time            : %.4g %s.\n", elapsed >= 1 ? elapsed : elapsed * 1e3, elapsed >= 1 ? "s" : "ms");
         printf("Number of LPs solved: %ld.\n", info.lps);

@@ -141,3 +141,39 @@ int bslv_sol_write3(bslv_poly *poly, const char *base, const char *suffix, int s
     free(pu); free(pi); free(du); free(di); free(X); free(Y); free(E); free(I); free(DE); free(pmap); free(dmap);
     return err ? BSLV_E_ARG : 0;
 }
+
+int bslv_sol_write_preimages(bslv_benson *eng, const char *base, const char *suffix, int m, int n, int optdir, int c_dir)
+{
+    bslv_poly *poly = bslv_benson_poly(eng);
+    const int d = bslv_poly_dim(poly), nv = bslv_poly_nprimal(poly), nf = bslv_poly_ndual(poly);
+    unsigned char *pu = (unsigned char *)malloc(nv + 1), *pi = (unsigned char *)malloc(nv + 1);
+    unsigned char *du = (unsigned char *)malloc(nf + 1), *di = (unsigned char *)malloc(nf + 1);
+    double *X = (double *)malloc((size_t)(nv + 1) * d * sizeof(double)), *Y = (double *)malloc((size_t)(nf + 1) * d * sizeof(double));
+    int rc;
+    if ((rc = bslv_poly_get_primal(poly, pu, pi, NULL, X)) || (rc = bslv_poly_get_dual(poly, du, di, Y))) return rc;
+    char path[1024];
+    double *row = (double *)malloc((size_t)(m + n + d + 1) * sizeof(double));
+    snprintf(path, sizeof path, "%s_pre_img_p%s", base, suffix);
+    FILE *f = fopen(path, "w");
+    if (!f) return BSLV_E_ARG;
+    for (int i = 0; i < nv; i++) {
+        if (!pu[i]) continue;
+        if (bslv_benson_preimage_p(eng, i, row)) for (int k = 0; k < n; k++) row[k] = 0.0;
+        for (int k = 0; k < n; k++) fprintf(f, k ? " %.14g" : "%.14g", row[k]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    snprintf(path, sizeof path, "%s_pre_img_d%s", base, suffix);
+    f = fopen(path, "w");
+    if (!f) return BSLV_E_ARG;
+    for (int k2 = 0; k2 < nf; k2++) {
+        if (!du[k2]) continue;
+        if (di[k2] || bslv_benson_preimage_d(eng, k2, row)) for (int k = 0; k < m + d; k++) row[k] = 0.0;
+        else { for (int k = 0; k < m; k++) row[k] *= optdir; for (int k = 0; k < d; k++) row[m + k] *= c_dir; }
+        for (int k = 0; k < m + d; k++) fprintf(f, k ? " %.14g" : "%.14g", row[k]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    free(pu); free(pi); free(du); free(di); free(X); free(Y); free(row);
+    return 0;
+}

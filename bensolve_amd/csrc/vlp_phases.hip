@@ -177,7 +177,7 @@ static int phase0(const Problem &pb, Sol &S, double eps_phase0, int *status, lon
     const int q = pb.q, p = S.p, d = q - 1;
     bslv_benson *h = nullptr;
     int rc = bslv_benson_create_ex(&h, pb.m, pb.n, q, pb.A, pb.P, pb.rtype, pb.rlb, pb.rub, pb.ctype, pb.clb, pb.cub,
-                                   S.Z.data(), p, S.c.data(), nullptr /* eta = 0 */, 1, 1e-7, 4);
+                                   S.Z.data(), p, S.c.data(), nullptr /* eta = 0 */, 1, 0, 1e-7, 4);
     if (rc) return rc;
     auto done = [&](int r) { bslv_benson_destroy(h); return r; };
     bslv_lpq *lp = bslv_benson_lp(h);
@@ -253,7 +253,7 @@ static int phase1_primal(const Problem &pb, Sol &S, double eps_phase1, double ep
     const int q = pb.q;
     bslv_benson *h = nullptr;
     int rc = bslv_benson_create_ex(&h, pb.m, pb.n, q, pb.A, pb.P, pb.rtype, pb.rlb, pb.rub, pb.ctype, pb.clb, pb.cub,
-                                   S.Z.data(), S.p, S.c.data(), S.eta.data(), 1, eps_benson, std::max(4 * batch + 64, 64));
+                                   S.Z.data(), S.p, S.c.data(), S.eta.data(), 1, 0, eps_benson, std::max(4 * batch + 64, 64));
     if (rc) return rc;
     auto done = [&](int r) { bslv_benson_destroy(h); return r; };
     int vst = 0;
@@ -455,6 +455,44 @@ int bslv_cone_vertenum(const double *gen, int n_in, int dim, double **prim, int 
 static thread_local int g_alg_phase1_dual = 0;
 int bslv_vlp_set_alg_phase1(int dual) { g_alg_phase1_dual = dual != 0; return 0; }
 
+// "-s" (opt->solution == PRE_IMG_ON) for the calls that follow on this thread: the phase-2 engine keeps pre-images
+static thread_local int g_preimages = 0;
+int bslv_vlp_set_preimages(int on) { g_preimages = on != 0; return 0; }
+
+// pre-images of the extreme DIRECTIONS of the upper image (bslv_algs.c:1083-1112): x of the homogeneous P2 with the bound
+// Z'd on the cone rows and the eta row switched off, one LP per direction
+static int direction_preimages(const Problem &pb, const Sol &S, bslv_benson *eng, long *lps)
+{
+    const int q = pb.q, p = S.p;
+    bslv_poly *poly = bslv_benson_poly(eng);
+    const int np = bslv_poly_nprimal(poly);
+    std::vector<unsigned char> pu(np), pi(np), ps(np);
+    std::vector<double> pc((size_t)np * q);
+    int rc;
+    if ((rc = bslv_poly_get_primal(poly, pu.data(), pi.data(), ps.data(), pc.data()))) return rc;
+    bslv_benson *hh = nullptr;
+    if ((rc = bslv_benson_create_ex(&hh, pb.m, pb.n, q, pb.A, pb.P, pb.rtype, pb.rlb, pb.rub, pb.ctype, pb.clb, pb.cub,
+                                    S.Z.data(), p, S.c.data(), nullptr, 1, 0, 1e-7, 4))) return rc;
+    auto done = [&](int r) { bslv_benson_destroy(hh); return r; };
+    bslv_lpq *lp = bslv_benson_lp(hh);
+    int M, N, folded;
+    bslv_benson_lp_dims(hh, &M, &N, &folded);
+    if ((rc = bslv_lpq_reset_slot(lp, 0))) return done(rc);
+    const int zero = 0;
+    std::vector<double> ub(p), x(pb.n);
+    for (int i = 0; i < np; i++) {
+        if (!pu[i] || !pi[i]) continue;
+        for (int j = 0; j < p; j++) { double s = 0; for (int k = 0; k < q; k++) s += S.Z[(size_t)k * p + j] * pc[(size_t)i * q + k]; ub[j] = s; }
+        int st;
+        if ((rc = solve0(lp, p, ub.data(), &st))) return done(rc);
+        if (st != BSLV_LP_OPTIMAL) { set_error("pre-image of a direction: LP status %d (the reference asserts optimality, bslv_algs.c:1107)", st); return done(BSLV_E_STATE); }
+        ++*lps;
+        if ((rc = bslv_lpq_get_primal(lp, 1, &zero, M, pb.n, x.data()))) return done(rc);
+        if ((rc = bslv_benson_set_preimage_p(eng, i, x.data()))) return done(rc);
+    }
+    return done(0);
+}
+
 // Shared front of the two entry points: sol_init, the sign normalisation, phases 0 and 1 (primal algorithm) unless bounded.
 // Returns with *vlp_status != 0 when the run ends here (input error, totally unbounded, no vertex).
 static int front(int m, int n, int q, const double *A, const double *P, const char *rtype, const double *rlb, const double *rub,
@@ -522,7 +560,7 @@ int bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P,
                     eps_benson_phase1, batch, g_alg_phase1_dual, S, Pn, &lps, &steps, vlp_status, info))) return rc;
     if (*vlp_status) return 0;
     bslv_benson *h = nullptr;
-    if ((rc = bslv_benson_create_ex(&h, m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub, S.R.data(), S.r, S.c.data(), S.eta.data(), 0,
+    if ((rc = bslv_benson_create_ex(&h, m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub, S.R.data(), S.r, S.c.data(), S.eta.data(), 0, g_preimages ? BSLV_BENSON_PREIMAGES : 0,
                                     eps_benson_phase2, std::max(4 * batch + 64, 64)))) return rc;
     int vst = 0;
     if ((rc = bslv_benson_start(h, &vst))) { bslv_benson_destroy(h); return rc; }
@@ -533,6 +571,10 @@ int bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P,
         return 0;
     }
     if ((rc = run_engine(h, batch, &lps, &steps))) { bslv_benson_destroy(h); return rc; }
+    if (g_preimages) {
+        Problem pb{m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub};
+        if ((rc = direction_preimages(pb, S, h, &lps))) { bslv_benson_destroy(h); return rc; }
+    }
     *engine_out = h;
     *vlp_status = 4;
     fill_info(info, S, optdir, lps, steps);

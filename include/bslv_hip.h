@@ -182,7 +182,14 @@ int  bslv_benson_create(bslv_benson **out, int m, int n, int q, const double *A,
 int  bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *A, const double *P,
                            const char *rtype, const double *rlb, const double *rub,
                            const char *ctype, const double *clb, const double *cub,
-                           const double *R, int r, const double *c, const double *eta, int hom, double eps, int pool_slots);
+                           const double *R, int r, const double *c, const double *eta, int hom, int flags, double eps, int pool_slots);
+/* flags of bslv_benson_create_ex.  PREIMAGES = option -s (opt->solution == PRE_IMG_ON): the engine keeps x of every confirmed
+ * vertex and (u, w) of every cut (bslv_algs.c:1064-1079); every row of A stays in the LP (no presolve) */
+enum { BSLV_BENSON_PREIMAGES = 2 };
+/* 0 + data, or 1 when nothing is stored for that element */
+int  bslv_benson_preimage_p(const bslv_benson *h, int element, double *x /* n */);
+int  bslv_benson_preimage_d(const bslv_benson *h, int facet, double *uw /* m + q */);
+int  bslv_benson_set_preimage_p(bslv_benson *h, int element, const double *x /* n */);
 void bslv_benson_destroy(bslv_benson *h);
 int  bslv_benson_start(bslv_benson *h, int *vlp_status /* 0 ok, 1 infeasible, 2 unbounded */);
 int  bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int *n_local, int *n_total);
@@ -242,6 +249,9 @@ int  bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
 /* "-A dual" (opt->alg_phase1, bslv_main.c:283-296): phase 1 of the calls that follow on this thread runs the dual variant
  * (phase1_dual, bslv_algs.c:1248-1371) instead of phase1_primal */
 int  bslv_vlp_set_alg_phase1(int dual);
+/* "-s" (opt->solution == PRE_IMG_ON) for the calls of bslv_vlp_solve_primal that follow on this thread: the phase-2 engine keeps
+ * the pre-images (BSLV_BENSON_PREIMAGES) and the directions of the upper image get theirs (bslv_algs.c:1083-1112) */
+int  bslv_vlp_set_preimages(int on);
 void bslv_vlp_info_free(bslv_vlp_info *info);
 /* cone_vertenum: prim = the non-redundant generators among gen (dim x n_prim), dual = generators of the dual cone
  * (dim x n_dual); malloc'ed, free with bslv_free.  rc_out 1: the cone has no interior (poly__intl_apprx failed). */
@@ -261,6 +271,11 @@ int  bslv_sol_write(bslv_poly *poly, const char *base, const char *suffix, int o
 /* the same with the two sign changes of poly_trans_primal (bslv_algs.c:221-229) spelled out (bslv_vlp_info) */
 int  bslv_sol_write2(bslv_poly *poly, const char *base, const char *suffix, int negate_primal, int negate_dual_last, long *counts);
 /* swap != 0: the engine's primal side is the LOWER image (dual algorithm; poly_output(..., SWAP, ...), bslv_algs.c:1566-1573) */
+/* <base>_pre_img_p<suffix> / _pre_img_d<suffix> (poly__primg2file, bslv_poly.c:362-380; poly_output :120-139): one row per
+ * element in the order of the _img_ files: x (n values) of the upper image's elements, (u, w) (m + q values) of the lower
+ * image's vertices, zeros where nothing is stored (directions of the lower image, :1114-1121).  u is multiplied by optdir
+ * and w by c_dir as the reference stores them (:1068-1070). */
+int  bslv_sol_write_preimages(bslv_benson *eng, const char *base, const char *suffix, int m, int n, int optdir, int c_dir);
 int  bslv_sol_write3(bslv_poly *poly, const char *base, const char *suffix, int swap, int negate_upper, int negate_lower_last, long *counts);
 
 #ifdef __cplusplus

@@ -118,3 +118,43 @@ def test_cli_ex01_known_answer(tmp_path):
     t, X, _ = read_img(base + "_img_p.sol")
     got = sorted((int(a), round(float(x), 9) + 0.0, round(float(y), 9) + 0.0) for a, (x, y) in zip(t, X))
     assert got == sorted([(1, 0.0, 4.0), (1, -6.0, 6.0), (0, 1.0, 0.0), (0, -1.0, 1.0)])
+    # <name>.log carries the fields of the reference's log (bslv_main.c:346-397)
+    log = open(base + ".log").read()
+    for frag in ("Problem parameters", "problem rows:            2", "problem columns:         2", "bounded:            no (run phases 0 to 2)",
+                 "alg_phase2:         primal", "# primal solution points:           2", "# primal solution directions:       2", "# LPs:"):
+        assert frag in log, (frag, log)
+    assert open(base + "_c.sol").read().split() == ["1", "1"]
+
+
+@pytest.mark.parametrize("m,n,q,seed,bounded", [(30, 15, 3, 5, True), (20, 10, 2, 3, False)])
+def test_cli_solution_files(tmp_path, m, n, q, seed, bounded):
+    """Option -s (opt->solution == PRE_IMG_ON): <name>_pre_img_p.sol holds an x for every element of the upper image (its
+    image P x is the vertex), <name>_pre_img_d.sol a dual solution (u, w) for every vertex of the lower image: u >= 0 on the
+    cover rows, A'u <= P'w (the columns are x >= 0), b'u = y*_q, w = (y*_1 .. y*_{q-1}, 1 - sum)."""
+    prob = synth.covering_vlp(m, n, q, seed)
+    path = os.path.join(tmp_path, "prob.vlp")
+    synth.write_vlp(prob, path)
+    base = os.path.join(tmp_path, "hip")
+    r = subprocess.run([CLI, path, "-s", "-m", "1", "-B", "32", "-o", base] + (["-b"] if bounded else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.array([[float(x) for x in l.split()] for l in open(base + "_img_p.sol").read().strip().splitlines()])
+    pre = np.array([[float(x) for x in l.split()] for l in open(base + "_pre_img_p.sol").read().strip().splitlines()])
+    assert pre.shape == (len(img), n)
+    pts = img[:, 0] == 1
+    assert pts.sum() >= 3
+    X = pre[pts]
+    np.testing.assert_allclose(X @ prob["P"].T, img[pts][:, 1:], rtol=1e-7, atol=1e-7)
+    assert np.all(X >= -1e-9) and np.all(X @ prob["A"].T >= 1 - 1e-7)               # feasible points
+    dirs = pre[~pts]
+    assert np.all(dirs >= -1e-9) and np.all(dirs @ prob["A"].T >= -1e-7)             # recession directions of the feasible set
+    imd = np.array([[float(x) for x in l.split()] for l in open(base + "_img_d.sol").read().strip().splitlines()])
+    prd = np.array([[float(x) for x in l.split()] for l in open(base + "_pre_img_d.sol").read().strip().splitlines()])
+    assert prd.shape == (len(imd), m + q)
+    vd = imd[:, 0] == 1
+    U, W, Ys = prd[vd][:, :m], prd[vd][:, m:], imd[vd][:, 1:]
+    assert np.all(U >= -1e-9)
+    np.testing.assert_allclose(W[:, :-1], Ys[:, :-1], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(W.sum(axis=1), 1.0, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(U.sum(axis=1), Ys[:, -1], rtol=1e-7, atol=1e-7)      # b = (1..1): dual objective = y*_q
+    assert np.all(U @ prob["A"] <= W @ prob["P"] + 1e-7)
+    assert "solution:           on" in open(base + ".log").read()
