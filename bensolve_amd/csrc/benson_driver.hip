@@ -30,6 +30,7 @@ struct bslv_benson {
     int m = 0, n = 0, q = 0, r = 0, M = 0, N = 0;     // m: rows of A left after the presolve
     int rows_folded = 0;                              // singleton rows of A turned into column bounds
     bool hom = false;                                 // homogeneous problem (phases 0 and 1)
+    long tot_retries = 0;                             // LPs solved again from the root tableau / the standard basis
     // option -s (opt->solution == PRE_IMG_ON): x of every confirmed vertex, (u, w) of every cut (bslv_algs.c:1064-1079)
     bool want_primg = false;
     int m_orig = 0;                                   // rows of A as given (pre-images need every row: no presolve)
@@ -61,6 +62,7 @@ struct bslv_benson {
     int policy = 1;                                   // 1: newest vertices first (depth first), 2: spread over the whole queue
     std::vector<double> slot_src;                     // per slot: vertex its LP was solved for (pool_slots x q)
     std::vector<char> slot_valid;
+    std::vector<int> slot_gen;                        // generations of warm starts between the root tableau and this slot
     // totals
     long tot_lps = 0, tot_cuts = 0, tot_pivots = 0;
 };
@@ -176,6 +178,7 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
     for (int s = pool_slots - 1; s >= 1; s--) h->free_slots.push_back(s);
     h->slot_src.assign((size_t)pool_slots * q, 0.0);
     h->slot_valid.assign(pool_slots, 0);
+    h->slot_gen.assign(pool_slots, 0);
     *out = h;
     return 0;
 }
@@ -293,6 +296,11 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
     return 0;
 }
 
+static int gen_max()      // BSLV_GEN_MAX: test hook
+{
+    static const int v = getenv("BSLV_GEN_MAX") ? std::max(1, atoi(getenv("BSLV_GEN_MAX"))) : 64;
+    return v;
+}
 static int take_slot(bslv_benson *h)      // caller holds slot_mu
 {
     if (h->free_slots.empty()) {
@@ -370,6 +378,10 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
             s = -1;
         }
         if (s < 0) { set_error("tableau pool exhausted (%d slots)", h->pool_slots); return BSLV_E_NOMEM; }
+        // a tableau is never refactorised: bound the chain of rank-1 updates a slot carries by restarting from the root
+        // tableau (slot 0) every 64 generations (gen_max()) -- a few more pivots for that LP, rounding drift that cannot pile up
+        if (h->slot_gen[src[k]] >= gen_max()) src[k] = 0;
+        h->slot_gen[s] = h->slot_gen[src[k]] + 1;
         dst[k] = s;
         B.l_slot[k] = s;
         const double *v = &B.b_val[(size_t)B.l_pos[k] * q];
@@ -385,6 +397,34 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
     std::vector<int> st(nl), it(nl);
     int rc;
     if ((rc = bslv_lpq_solve_batch(h->lp, nl, src.data(), dst.data(), vlo.data(), vup.data(), st.data(), it.data()))) return rc;
+    {
+        // The reference's retry (bslv_lp.c:222-227: undefined -> standard basis -> solve again), in two stages.  A tableau is
+        // handed down from parent to child without ever being refactorised; after hundreds of generations (ex07: 3400 outer
+        // iterations) the reduced costs of a parent can have drifted past the dual feasibility tolerance, which k_prep reports
+        // as UNDEFINED.  Such LPs start again from the root tableau (slot 0: the first optimal basis, one generation old), and
+        // if that fails too, from the standard basis.
+        std::vector<int> redo;
+        for (int k = 0; k < nl; k++) if (st[k] == BSLV_LP_UNDEFINED) redo.push_back(k);
+        for (int stage = 0; stage < 2 && !redo.empty(); stage++) {
+            const int nr = (int)redo.size();
+            std::vector<int> s2(nr), d2(nr), st2(nr), it2(nr);
+            std::vector<double> lo2((size_t)nr * r, -INFINITY), up2((size_t)nr * r);
+            for (int t = 0; t < nr; t++) {
+                d2[t] = dst[redo[t]];
+                s2[t] = stage == 0 ? 0 : d2[t];
+                memcpy(&up2[(size_t)t * r], &vup[(size_t)redo[t] * r], r * sizeof(double));
+                if (stage == 1 && (rc = bslv_lpq_reset_slot(h->lp, d2[t]))) return rc;
+            }
+            if ((rc = bslv_lpq_solve_batch(h->lp, nr, s2.data(), d2.data(), lo2.data(), up2.data(), st2.data(), it2.data()))) return rc;
+            std::vector<int> still;
+            for (int t = 0; t < nr; t++) {
+                st[redo[t]] = st2[t]; it[redo[t]] += it2[t];
+                if (st2[t] == BSLV_LP_UNDEFINED) still.push_back(redo[t]);
+            }
+            h->tot_retries += nr;
+            redo.swap(still);
+        }
+    }
     std::vector<double> ww((size_t)nl * q), yy((size_t)nl * q), zz(nl);
     if ((rc = bslv_lpq_get_dual(h->lp, nl, dst.data(), h->m, q, ww.data()))) return rc;                 // bslv_algs.c:1050
     if ((rc = bslv_lpq_get_primal(h->lp, nl, dst.data(), h->M + h->n, q, yy.data()))) return rc;        // :1055
@@ -439,10 +479,10 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     std::vector<int> confirmed, cut_src;
     std::vector<double> cuts;
     std::unordered_set<std::string> dedupe;
-    long nfail = 0, nduplicate = 0;
+    long nfail = 0, nduplicate = 0, nstatus[5] = {0, 0, 0, 0, 0};
     for (int k : order) {
         const double *rec = records + (size_t)k * RL;
-        if ((int)rec[1] != BSLV_LP_OPTIMAL) { nfail++; continue; }
+        if ((int)rec[1] != BSLV_LP_OPTIMAL) { nfail++; nstatus[std::min(std::max((int)rec[1], 0), 4)]++; continue; }
         if (rec[2] != 0.0) {
             // sibling vertices (children of one cut) mostly see the SAME facet of the upper image: an exact duplicate of
             // a cut already in this batch has no violating vertex once the first copy is applied (the reference's
@@ -458,7 +498,11 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
         else confirmed.push_back((int)rec[0]);                                                           // :1074-1079
     }
     int rc;
-    if (nfail) { set_error("%ld LP(s) of the batch did not reach optimality (the reference asserts here, bslv_algs.c:1049)", nfail); return BSLV_E_STATE; }
+    if (nfail) {
+        set_error("%ld LP(s) of the batch did not reach optimality: %ld infeasible, %ld unbounded, %ld undefined (iteration limit or no dual feasible start) "
+                  "(the reference asserts here, bslv_algs.c:1049)%s", nfail, nstatus[0], nstatus[1], nstatus[2] + nstatus[3], h->hom ? " [homogeneous problem, phase 1]" : "");
+        return BSLV_E_STATE;
+    }
     if (!confirmed.empty() && (rc = bslv_poly_mark(h->poly, (int)confirmed.size(), confirmed.data()))) return rc;
     if (h->want_primg && !confirmed.empty()) {                                       // x of the confirmed vertices (:1078)
         std::unordered_map<int, int> slot_of;

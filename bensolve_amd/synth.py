@@ -123,3 +123,38 @@ def write_vlp(prob, path):
                 elif t == "s":
                     f.write("%s %d s %.17g\n" % (kind, k + 1, lb[k]))
         f.write("e\n")
+
+
+def read_vlp(path):
+    """Line-level reader of the .vlp format into the problem dict the engines take; the C reader
+    (bslv_vlp_read) is the product's, this one serves scripts and tests.  Defaults as the reference: rows 'f', columns 's'."""
+    d = None
+    for line in open(path):
+        t = line.split()
+        if not t or t[0] == "c":
+            continue
+        if t[0] == "p":
+            m, n, nz, q, nzo = (int(x) for x in t[3:8])
+            d = dict(m=m, n=n, q=q, optdir=1 if t[2] == "min" else -1, A=np.zeros((m, n)), P=np.zeros((q, n)),
+                     rtype=np.full(m, ord("f"), np.uint8), ctype=np.full(n, ord("s"), np.uint8), rlb=np.zeros(m), rub=np.zeros(m),
+                     clb=np.zeros(n), cub=np.zeros(n), c=np.zeros(q), cone_kind=0 if len(t) <= 8 else (1 if t[8] == "cone" else 2),
+                     gen=np.zeros((q, int(t[9]))) if len(t) > 8 else None)
+        elif t[0] == "a":
+            d["A"][int(t[1]) - 1, int(t[2]) - 1] = float(t[3])
+        elif t[0] == "o":
+            d["P"][int(t[1]) - 1, int(t[2]) - 1] = float(t[3])
+        elif t[0] == "k":
+            if int(t[2]) == 0:
+                d["c"][int(t[1]) - 1] = float(t[3])
+            else:
+                d["gen"][int(t[1]) - 1, int(t[2]) - 1] = float(t[3])
+        elif t[0] in "ij":
+            ty, lb, ub = (d["rtype"], d["rlb"], d["rub"]) if t[0] == "i" else (d["ctype"], d["clb"], d["cub"])
+            k = int(t[1]) - 1
+            ty[k] = ord(t[2])
+            rest = [float(x) for x in t[3:]]
+            if t[2] in "lds":
+                lb[k] = rest.pop(0)
+            if t[2] in "ud":
+                ub[k] = rest.pop(0)
+    return d

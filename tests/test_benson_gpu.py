@@ -217,3 +217,34 @@ def test_pipelined_lp_poly_overlap_matches_oracle(m, n, q, seed, batch):
     assert np.all(d["ps"][d["pu"].astype(bool)] == 1)         # every live element was processed
     eng.close()
     ph.assert_benson_results_agree(got, exp)
+
+
+def test_restart_from_the_root_tableau_gives_the_same_image():
+    """A tableau is handed from parent to child without refactorisation; the driver bounds the chain by restarting from the
+    root tableau every 64 generations (ex07 needs it after ~3000 outer iterations).  Forced to every 2nd generation here, in a
+    subprocess (the limit is read once per process): same upper image as the oracle, more pivots."""
+    import subprocess, sys, json
+    code = r"""
+import json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from bensolve_amd import synth
+from bensolve_amd.benson import BensonEngine
+import poly_harness as ph
+prob = synth.covering_vlp(60, 30, 3, 7)
+eng = BensonEngine(prob, eps=1e-9, pool_slots=4 * 16 + 64)
+assert eng.start() == 0
+eng.run(16)
+eng.poly_call("dual_adjacency")
+c = ph.canonical(eng.poly_dump(), decimals=6)
+print(json.dumps(dict(X=c["X"].tolist(), pi=c["pi"].tolist(), pivots=eng.totals()["pivots"], lps=eng.totals()["lps"])))
+""" % (os.path.dirname(HERE), HERE)
+    out = {}
+    for gm in ("2", "64"):
+        env = dict(os.environ, BSLV_GEN_MAX=gm)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[gm] = json.loads(r.stdout.strip().splitlines()[-1])
+    np.testing.assert_allclose(np.array(out["2"]["X"]), np.array(out["64"]["X"]), rtol=1e-7, atol=1e-7)
+    assert out["2"]["pi"] == out["64"]["pi"]
+    assert out["2"]["pivots"] > out["64"]["pivots"]
