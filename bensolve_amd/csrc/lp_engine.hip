@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         if (tid == 0) { s_cnt = 0; s_nboxed = 0; s_stop = 0; }
         for (int j = tid; j < N; j += NT) sflag[j] = 0;
         __syncthreads();
-        for (int j = tid; j < N; j += NT) {
+        if (cap2 > 0) for (int j = tid; j < N; j += NT) {
             int st = nstat[j];
             if (st == NS_S) continue;
             double a = sgn * row[j];
@@ -684,7 +684,9 @@ __global__ void k_after_flush(BatchView Bv, int it)
 //        others:   T[i][j] -= f_si * prow_s[j] (j != q_s), T[i][q_s] = f_si          (f_si from k_select)
 //      and the row is written to the LP's own slot; with MODE_REFRESH beta_i = T_i . xN is recomputed from the finished row.
 //      Algorithmic traffic of one pass: one read + one write of the tableau, whatever the number of pending pivots. ----
-__global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8, 16 or 32 */)
+//      wide != 0 (rows of more than ~3000 columns: KP pivot rows do not fit in LDS): the pivot rows are read from global
+//      memory instead -- every row tile of an LP reads the same KP rows, which the L2 / MALL serve after the first tile. ----
+__global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8, 16 or 32 */, int wide)
 {
     extern __shared__ double s_rows[];           // KP pivot rows
     __shared__ PivDesc s_pd[KP];
@@ -700,10 +702,11 @@ __global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, in
         double *T = L.T + (size_t)slot * L.slotT;
         double *beta = L.beta + (size_t)slot * L.Mp1p;
         const double *pcol0 = Bv.pcol + (size_t)b * KP * L.Mp1p;
+        const double *rowsp = wide ? Bv.prow + (size_t)b * KP * ld : s_rows;
         {
             const double2 *g = reinterpret_cast<const double2 *>(Bv.prow + (size_t)b * KP * ld);
             double2 *s2 = reinterpret_cast<double2 *>(s_rows);
-            for (int j2 = threadIdx.x; j2 < np * ld2; j2 += NT) s2[j2] = g[j2];
+            if (!wide) for (int j2 = threadIdx.x; j2 < np * ld2; j2 += NT) s2[j2] = g[j2];
             if (threadIdx.x < np) s_pd[threadIdx.x] = Bv.desc[(size_t)b * KP + threadIdx.x];
         }
         __syncthreads();
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, in
 #pragma unroll
                 for (int s = 0; s < KP; s++) {
                     if (s >= np) break;
-                    const double2 pr = reinterpret_cast<const double2 *>(s_rows + (size_t)s * ld)[j2];
+                    const double2 pr = reinterpret_cast<const double2 *>(rowsp + (size_t)s * ld)[j2];
                     const int q2 = s_pd[s].q >> 1, qodd = s_pd[s].q & 1;
                     if (isr[s]) { const double p = s_pd[s].p; v.x = -pr.x * p; v.y = -pr.y * p; if (j2 == q2) { if (qodd) v.y = p; else v.x = p; } }
                     else { const double fs = f[s]; v.x = fma(-fs, pr.x, v.x); v.y = fma(-fs, pr.y, v.y); if (j2 == q2) { if (qodd) v.y = fs; else v.x = fs; } }
@@ -1079,7 +1082,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     int rc;
     if ((rc = ensure_batch(h, B))) return rc;
     LpView &L = h->L;
-    if ((size_t)KP * L.ld * sizeof(double) > h->flush_lds_max) { set_error("rows too long for the LDS-staged pivot rows (N=%d)", L.N); return BSLV_E_CAPACITY; }
+    const int wide = (size_t)KP * L.ld * sizeof(double) > h->flush_lds_max;      // pivot rows from global memory in k_flush
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
     HIP_TRY(hipMemcpyAsync(h->src_d, src, B * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1112,7 +1115,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     }
     hipLaunchKernelGGL(k_init, dim3(tiles, B), dim3(NT), 0, s, L, bv, B);
     HIP_TRY(hipGetLastError());
-    const size_t lds = (size_t)KP * L.ld * sizeof(double);
+    const size_t lds = wide ? 0 : (size_t)KP * L.ld * sizeof(double);
     // bound flipping ratio test only where a variable has two finite, non-artificial bounds
     bool bfrt = h->has_boxed || L.objmode;        // (the primal steps live in the extended selection)
     if (!bfrt && L.vcnt > 0)
@@ -1120,11 +1123,13 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     if (getenv("BSLV_LP_EXT")) bfrt = atoi(getenv("BSLV_LP_EXT")) != 0;      // test hook: force the extended selection on / off
     int cap2 = 2;
     while (cap2 < L.N) cap2 <<= 1;
-    const size_t sel_lds = (size_t)cap2 * (sizeof(double) + sizeof(int)) + (size_t)L.N;
+    size_t sel_lds = (size_t)cap2 * (sizeof(double) + sizeof(int)) + (size_t)L.N;
+    if (bfrt && sel_lds > 144 * 1024) { cap2 = 0; sel_lds = (size_t)L.N; }     // rows too long for the in-LDS sort: extended selection without the long-step part
     if (bfrt && sel_lds > h->select_lds_max) {
         if (sel_lds <= 144 * 1024 && hipFuncSetAttribute((const void *)k_select<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds) == hipSuccess) h->select_lds_max = sel_lds;
-        else bfrt = false;       // rows too long for the in-LDS sort: plain ratio test
+        else bfrt = false;
     }
+    if (L.objmode && !bfrt) { set_error("bslv_lpq_solve_batch_obj: rows too long for the extended selection (N=%d)", L.N); return BSLV_E_CAPACITY; }
     L.trace = getenv("BSLV_LP_TRACE") ? atoi(getenv("BSLV_LP_TRACE")) : -1;
     L.stall_limit = getenv("BSLV_STALL_LIMIT") ? atoi(getenv("BSLV_STALL_LIMIT")) : STALL_LIMIT;
     L.pert_scale = getenv("BSLV_PERT_SCALE") ? atof(getenv("BSLV_PERT_SCALE")) : 1.0;
@@ -1153,7 +1158,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
             // few LPs left: smaller row tiles keep >= ~2k workgroups in flight
             const int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : 8);
             const int ntile = (L.Mp1 + tr - 1) / tr;
-            hipLaunchKernelGGL(k_flush, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), lds, s, L, bv, it, ntile, tr);
+            hipLaunchKernelGGL(k_flush, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), lds, s, L, bv, it, ntile, tr, wide);
             if (h->profile) { HIP_TRY(hipEventRecord(h->evpool[nev].second, s)); nev++; }
             hipLaunchKernelGGL(k_after_flush, dim3((running + 255) / 256), dim3(256), 0, s, bv, it);
         }
