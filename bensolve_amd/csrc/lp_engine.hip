@@ -686,7 +686,8 @@ __global__ void k_after_flush(BatchView Bv, int it)
 //      Algorithmic traffic of one pass: one read + one write of the tableau, whatever the number of pending pivots. ----
 //      wide != 0 (rows of more than ~3000 columns: KP pivot rows do not fit in LDS): the pivot rows are read from global
 //      memory instead -- every row tile of an LP reads the same KP rows, which the L2 / MALL serve after the first tile. ----
-__global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8, 16 or 32 */, int wide)
+template <bool WIDE>
+__global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8, 16 or 32 */)
 {
     extern __shared__ double s_rows[];           // KP pivot rows
     __shared__ PivDesc s_pd[KP];
@@ -702,11 +703,11 @@ __global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, in
         double *T = L.T + (size_t)slot * L.slotT;
         double *beta = L.beta + (size_t)slot * L.Mp1p;
         const double *pcol0 = Bv.pcol + (size_t)b * KP * L.Mp1p;
-        const double *rowsp = wide ? Bv.prow + (size_t)b * KP * ld : s_rows;
+        const double *rowsg = Bv.prow + (size_t)b * KP * ld;
         {
             const double2 *g = reinterpret_cast<const double2 *>(Bv.prow + (size_t)b * KP * ld);
             double2 *s2 = reinterpret_cast<double2 *>(s_rows);
-            if (!wide) for (int j2 = threadIdx.x; j2 < np * ld2; j2 += NT) s2[j2] = g[j2];
+            if (!WIDE) for (int j2 = threadIdx.x; j2 < np * ld2; j2 += NT) s2[j2] = g[j2];
             if (threadIdx.x < np) s_pd[threadIdx.x] = Bv.desc[(size_t)b * KP + threadIdx.x];
         }
         __syncthreads();
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, in
 #pragma unroll
                 for (int s = 0; s < KP; s++) {
                     if (s >= np) break;
-                    const double2 pr = reinterpret_cast<const double2 *>(rowsp + (size_t)s * ld)[j2];
+                    const double2 pr = WIDE ? reinterpret_cast<const double2 *>(rowsg + (size_t)s * ld)[j2] : reinterpret_cast<const double2 *>(s_rows + (size_t)s * ld)[j2];
                     const int q2 = s_pd[s].q >> 1, qodd = s_pd[s].q & 1;
                     if (isr[s]) { const double p = s_pd[s].p; v.x = -pr.x * p; v.y = -pr.y * p; if (j2 == q2) { if (qodd) v.y = p; else v.x = p; } }
                     else { const double fs = f[s]; v.x = fma(-fs, pr.x, v.x); v.y = fma(-fs, pr.y, v.y); if (j2 == q2) { if (qodd) v.y = fs; else v.x = fs; } }
@@ -991,7 +992,7 @@ int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double 
     {   // k_flush stages KP pivot rows in LDS: wide problems (N > ~1300) need more than the default 64 KB
         const size_t want = (size_t)KP * h->L.ld * sizeof(double);
         if (want > h->flush_lds_max) {
-            if (want <= 144 * 1024 && hipFuncSetAttribute((const void *)k_flush, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) h->flush_lds_max = want;
+            if (want <= 144 * 1024 && hipFuncSetAttribute((const void *)k_flush<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) h->flush_lds_max = want;
             else (void)hipGetLastError();
         }
     }
@@ -1158,7 +1159,8 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
             // few LPs left: smaller row tiles keep >= ~2k workgroups in flight
             const int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : 8);
             const int ntile = (L.Mp1 + tr - 1) / tr;
-            hipLaunchKernelGGL(k_flush, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), lds, s, L, bv, it, ntile, tr, wide);
+            if (wide) hipLaunchKernelGGL(k_flush<true>, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), 0, s, L, bv, it, ntile, tr);
+            else hipLaunchKernelGGL(k_flush<false>, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), lds, s, L, bv, it, ntile, tr);
             if (h->profile) { HIP_TRY(hipEventRecord(h->evpool[nev].second, s)); nev++; }
             hipLaunchKernelGGL(k_after_flush, dim3((running + 255) / 256), dim3(256), 0, s, bv, it);
         }
