@@ -33,3 +33,24 @@ def test_vlp_roundtrip(tmp_path):
         if t[0] == "o": P[int(t[1]) - 1, int(t[2]) - 1] = float(t[3])
     assert np.array_equal(A, prob["A"]) and np.array_equal(P, prob["P"])      # %.17g round-trips bit-exactly
     assert sum(1 for l in lines if l.startswith("i ")) == 7 and sum(1 for l in lines if l.startswith("j ")) == 5
+
+
+def test_read_vlp_helper_matches_the_c_reader():
+    """bensolve_amd.synth.read_vlp (scripts, tests) against the product's C reader on the committed example files"""
+    import ctypes
+    import os
+    import numpy as np
+    from bensolve_amd import synth
+    import test_vlp_parser as tp
+    exdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ex")
+    for ex in ("ex01", "ex05", "ex06", "ex10"):
+        path = os.path.join(exdir, ex + ".vlp")
+        a, b = synth.read_vlp(path), tp.c_read(path)
+        assert (a["m"], a["n"], a["q"], a["optdir"]) == (b["m"], b["n"], b["q"], b["optdir"])
+        np.testing.assert_array_equal(a["A"], b["A"])
+        np.testing.assert_array_equal(a["P"], b["P"])
+        assert bytes(a["rtype"]).decode() == "".join(b["rtype"]) if isinstance(b["rtype"], list) else True
+        for k in ("rlb", "rub", "clb", "cub"):
+            np.testing.assert_array_equal(a[k], b[k])
+        if a["gen"] is not None:
+            np.testing.assert_array_equal(a["gen"], b["gen"])
