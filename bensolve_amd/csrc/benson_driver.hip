@@ -404,6 +404,7 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
         // as UNDEFINED.  Such LPs start again from the root tableau (slot 0: the first optimal basis, one generation old), and
         // if that fails too, from the standard basis.
         std::vector<int> redo;
+        if (getenv("BSLV_FORCE_RETRY")) for (int k = 1; k < nl; k += 2) st[k] = BSLV_LP_UNDEFINED;      // test hook: every other LP goes through the retry
         for (int k = 0; k < nl; k++) if (st[k] == BSLV_LP_UNDEFINED) redo.push_back(k);
         for (int stage = 0; stage < 2 && !redo.empty(); stage++) {
             const int nr = (int)redo.size();

@@ -240,11 +240,14 @@ c = ph.canonical(eng.poly_dump(), decimals=6)
 print(json.dumps(dict(X=c["X"].tolist(), pi=c["pi"].tolist(), pivots=eng.totals()["pivots"], lps=eng.totals()["lps"])))
 """ % (os.path.dirname(HERE), HERE)
     out = {}
-    for gm in ("2", "64"):
-        env = dict(os.environ, BSLV_GEN_MAX=gm)
+    for gm in ("2", "64", "retry"):
+        env = dict(os.environ, BSLV_GEN_MAX=gm) if gm != "retry" else dict(os.environ, BSLV_FORCE_RETRY="1")
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         out[gm] = json.loads(r.stdout.strip().splitlines()[-1])
     np.testing.assert_allclose(np.array(out["2"]["X"]), np.array(out["64"]["X"]), rtol=1e-7, atol=1e-7)
     assert out["2"]["pi"] == out["64"]["pi"]
     assert out["2"]["pivots"] > out["64"]["pivots"]
+    # the retry of undefined LPs (from the root tableau), forced on every other LP of every batch
+    np.testing.assert_allclose(np.array(out["retry"]["X"]), np.array(out["64"]["X"]), rtol=1e-7, atol=1e-7)
+    assert out["retry"]["pi"] == out["64"]["pi"] and out["retry"]["pivots"] > out["64"]["pivots"]

@@ -253,3 +253,35 @@ def test_forced_perturbation_and_primal_cleanup_reach_the_same_optimum(oracle, m
     np.testing.assert_allclose(obj, exp_obj, rtol=RTOL, atol=1e-9)
     _check_identities(model, V, obj, eng.dual(dst, model.w_first, q), eng.primal(dst, model.y_first, q))
     eng.close()
+
+
+def test_wide_rows_read_the_pivot_rows_from_global_memory(oracle):
+    """More than ~3000 columns: the six pending pivot rows of k_flush no longer fit in 144 KB of LDS and the kernel's wide
+    instance reads them from global memory.  Same objective values as the oracle."""
+    import oracle_api
+    m, n, q, seed, B = 24, 3300, 2, 12, 6
+    prob = synth.covering_vlp(m, n, q, seed)
+    model = P2Model(prob)
+    assert model.N * 8 * 6 > 144 * 1024
+    rng = np.random.default_rng(seed)
+    V = _random_V(model, prob, rng, B)
+    ub = model.ub_for(V)
+    olp = oracle_api.OracleLP(model.L, model.lo, model.up, model.cost)
+    exp_obj = np.empty(B)
+    for b in range(B):
+        for j in range(model.r):
+            olp.set_bound(model.var_first + j, -np.inf, ub[b, j])
+        assert olp.solve(1) == 4
+        exp_obj[b] = olp.obj()
+    olp.close()
+    eng = LpEngine.from_model(model, pool_slots=B + 1)
+    eng.reset_slot(0)
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+    assert st[0] == 4 and it[0] > 6
+    dst = np.arange(1, B + 1, dtype=np.int32)
+    st, it = eng.solve_batch(np.zeros(B, np.int32), dst, np.full((B, model.r), -np.inf), ub)
+    assert np.all(st == 4)
+    obj = eng.obj(dst)
+    np.testing.assert_allclose(obj, exp_obj, rtol=RTOL, atol=1e-9)
+    _check_identities(model, V, obj, eng.dual(dst, model.w_first, q), eng.primal(dst, model.y_first, q))
+    eng.close()
