@@ -64,7 +64,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
-    defaults = {"S-small": (2048, 20000), "S-mid": (1024, 800), "S-degenerate": (64, 4)}
+    defaults = {"S-small": (2048, 20000), "S-mid": (2048, 800), "S-degenerate": (64, 4)}
     B = args.batch or defaults.get(args.workload, (256, 50))[0]
     cpu_lps = args.cpu_lps or defaults.get(args.workload, (256, 50))[1]
     prob = synth.CONFIGS[args.workload]()
