@@ -37,7 +37,7 @@ def test_phase2_sets_match_oracle(m, n, q, seed, batch):
     assert tot["lps"] >= len(exp["X"]) - q
 
 
-@pytest.mark.parametrize("m,n,q,batch", [(24, 12, 3, 8), (60, 30, 3, 32), (60, 30, 4, 64), (120, 60, 4, 128)])
+@pytest.mark.parametrize("m,n,q,batch", [(24, 12, 3, 8), (60, 30, 3, 32), (60, 30, 4, 64), (120, 60, 4, 128), (60, 30, 5, 128), (40, 20, 6, 128)])
 def test_phase2_degenerate_family_matches_oracle(m, n, q, batch):
     """BASELINE.json configs[4] (S-degenerate: unit cube + integer cover rows, integer lattice objectives, free columns) at
     sizes the CPU oracle finishes: massively dual-degenerate LPs (ties in every ratio test, Bland's rule after the
