@@ -47,10 +47,10 @@ int main(int argc, char **argv)
             const char *v2 = ARG();
             if (!strcmp(v2, "dual")) dual2 = 1; else if (!strcmp(v2, "primal")) dual2 = 0; else { printf("option --alg_phase2 (-a): invalid argument\n"); return 1; }
         }
-        else if (!strcmp(o, "-s") || !strcmp(o, "--solution")) { presol = 1; bslv_vlp_set_preimages(1); }
+        else if (!strcmp(o, "-s") || !strcmp(o, "--solution")) presol = 1;
         else if (!strcmp(o, "-A") || !strcmp(o, "--alg_phase1")) {
             const char *v1 = ARG();
-            if (!strcmp(v1, "dual")) bslv_vlp_set_alg_phase1(dual1 = 1); else if (!strcmp(v1, "primal")) bslv_vlp_set_alg_phase1(dual1 = 0); else { printf("option --alg_phase1 (-A): invalid argument\n"); return 1; }
+            if (!strcmp(v1, "dual")) dual1 = 1; else if (!strcmp(v1, "primal")) dual1 = 0; else { printf("option --alg_phase1 (-A): invalid argument\n"); return 1; }
         }
         else if (!strcmp(o, "-E") || !strcmp(o, "--eps_phase1")) { eps1 = atof(ARG()); if (!(eps1 > 0)) { printf("option --eps_phase1 (-E): invalid argument\n"); return 1; } }
         else if (!strcmp(o, "-h") || !strcmp(o, "--help")) { usage(); return 1; }
@@ -77,10 +77,11 @@ int main(int argc, char **argv)
     int st = 0;
     if (msg >= 1) printf("running ... \n");
     bslv_poly *lower = NULL;
+    const int vflags = (dual1 ? BSLV_VLP_PHASE1_DUAL : 0) | (presol ? BSLV_VLP_PREIMAGES : 0);
     int rc = dual2 ? bslv_vlp_solve_dual2(v->m, v->n, q, v->A, v->P, v->rtype, v->rlb, v->rub, v->ctype, v->clb, v->cub,
-                                          v->optdir, v->cone_gen, v->gen, v->n_gen, v->c, bounded, 1e-8, 1e-8, eps1, eps, batch, &lower, &st, &info)
+                                          v->optdir, v->cone_gen, v->gen, v->n_gen, v->c, bounded, vflags, 1e-8, 1e-8, eps1, eps, batch, &lower, &st, &info)
                    : bslv_vlp_solve_primal(v->m, v->n, q, v->A, v->P, v->rtype, v->rlb, v->rub, v->ctype, v->clb, v->cub,
-                                           v->optdir, v->cone_gen, v->gen, v->n_gen, v->c, bounded, 1e-8, 1e-8, eps1, eps, batch, &h, &st, &info);
+                                           v->optdir, v->cone_gen, v->gen, v->n_gen, v->c, bounded, vflags, 1e-8, 1e-8, eps1, eps, batch, &h, &st, &info);
     if (rc) { printf("engine error %d: %s\n", rc, bslv_last_error()); return 3; }
     char cfile[1100];
     if (info.c) {                                                         /* bslv_vlp.c:833-842 */

@@ -451,14 +451,6 @@ int bslv_cone_vertenum(const double *gen, int n_in, int dim, double **prim, int 
     return 0;
 }
 
-// "-A dual": phase 1 by the dual variant for the calls that follow (opt->alg_phase1, bslv_main.c:283-296); per thread
-static thread_local int g_alg_phase1_dual = 0;
-int bslv_vlp_set_alg_phase1(int dual) { g_alg_phase1_dual = dual != 0; return 0; }
-
-// "-s" (opt->solution == PRE_IMG_ON) for the calls that follow on this thread: the phase-2 engine keeps pre-images
-static thread_local int g_preimages = 0;
-int bslv_vlp_set_preimages(int on) { g_preimages = on != 0; return 0; }
-
 // pre-images of the extreme DIRECTIONS of the upper image (bslv_algs.c:1083-1112): x of the homogeneous P2 with the bound
 // Z'd on the cone rows and the eta row switched off, one LP per direction
 static int direction_preimages(const Problem &pb, const Sol &S, bslv_benson *eng, long *lps)
@@ -544,7 +536,7 @@ int bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P,
                           const char *rtype, const double *rlb, const double *rub,
                           const char *ctype, const double *clb, const double *cub,
                           int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
-                          int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
+                          int bounded, int flags, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
                           int batch, bslv_benson **engine_out, int *vlp_status, bslv_vlp_info *info)
 {
     if (!engine_out || !vlp_status || m < 1 || n < 1 || q < 2 || !A || !P || !rtype || !ctype || batch < 1 || (cone_kind != 0 && (!gen || n_gen < 1))) {
@@ -557,10 +549,10 @@ int bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P,
     long lps = 0, steps = 0;
     int rc;
     if ((rc = front(m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, optdir, cone_kind, gen, n_gen, c_in, bounded, eps_phase0, eps_phase1,
-                    eps_benson_phase1, batch, g_alg_phase1_dual, S, Pn, &lps, &steps, vlp_status, info))) return rc;
+                    eps_benson_phase1, batch, (flags & BSLV_VLP_PHASE1_DUAL) != 0, S, Pn, &lps, &steps, vlp_status, info))) return rc;
     if (*vlp_status) return 0;
     bslv_benson *h = nullptr;
-    if ((rc = bslv_benson_create_ex(&h, m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub, S.R.data(), S.r, S.c.data(), S.eta.data(), 0, g_preimages ? BSLV_BENSON_PREIMAGES : 0,
+    if ((rc = bslv_benson_create_ex(&h, m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub, S.R.data(), S.r, S.c.data(), S.eta.data(), 0, (flags & BSLV_VLP_PREIMAGES) ? BSLV_BENSON_PREIMAGES : 0,
                                     eps_benson_phase2, std::max(4 * batch + 64, 64)))) return rc;
     int vst = 0;
     if ((rc = bslv_benson_start(h, &vst))) { bslv_benson_destroy(h); return rc; }
@@ -571,7 +563,7 @@ int bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P,
         return 0;
     }
     if ((rc = run_engine(h, batch, &lps, &steps))) { bslv_benson_destroy(h); return rc; }
-    if (g_preimages) {
+    if (flags & BSLV_VLP_PREIMAGES) {
         Problem pb{m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub};
         if ((rc = direction_preimages(pb, S, h, &lps))) { bslv_benson_destroy(h); return rc; }
     }
@@ -588,7 +580,7 @@ int bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
                          const char *rtype, const double *rlb, const double *rub,
                          const char *ctype, const double *clb, const double *cub,
                          int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
-                         int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
+                         int bounded, int flags, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
                          int batch, bslv_poly **lower_image_out, int *vlp_status, bslv_vlp_info *info)
 {
     if (!lower_image_out || !vlp_status || m < 1 || n < 1 || q < 2 || !A || !P || !rtype || !ctype || batch < 1 || (cone_kind != 0 && (!gen || n_gen < 1))) {
@@ -601,7 +593,7 @@ int bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
     long lps = 0, steps = 0;
     int rc;
     if ((rc = front(m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, optdir, cone_kind, gen, n_gen, c_in, bounded, eps_phase0, eps_phase1,
-                    eps_benson_phase1, batch, g_alg_phase1_dual, S, Pn, &lps, &steps, vlp_status, info))) return rc;
+                    eps_benson_phase1, batch, (flags & BSLV_VLP_PHASE1_DUAL) != 0, S, Pn, &lps, &steps, vlp_status, info))) return rc;
     if (*vlp_status) return 0;
     Problem pb{m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub};
     int vst = 0;

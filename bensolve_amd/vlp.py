@@ -37,7 +37,7 @@ def cone_vertenum(gen):
 
 
 def solve_primal(prob, cone_kind=0, gen=None, c=None, bounded=False, eps_phase0=1e-8, eps_phase1=1e-8, eps_benson_phase1=1e-7,
-                 eps_benson_phase2=1e-7, batch=256, alg_phase2="primal"):
+                 eps_benson_phase2=1e-7, batch=256, alg_phase2="primal", alg_phase1="primal", preimages=False):
     """prob: dict as bensolve_amd.synth builds them (P as in the file: not negated).  Returns dict(status, message, info...,
     dump = slot-indexed dump of the result polyhedron with the sign changes of poly_trans_primal applied).  alg_phase2 = "dual":
     phase2_dual; the dump is then given with the sides swapped back, so that X / pi are the upper image in both cases."""
@@ -52,14 +52,14 @@ def solve_primal(prob, cone_kind=0, gen=None, c=None, bounded=False, eps_phase0=
     h = vp()
     st = ctypes.c_int()
     info = VlpInfo()
-    lib.bslv_vlp_solve_primal.argtypes = [ctypes.c_int] * 3 + [vp] * 8 + [ctypes.c_int] * 2 + [vp, ctypes.c_int, vp, ctypes.c_int] + [ctypes.c_double] * 4 + [ctypes.c_int, vp, vp, vp]
+    lib.bslv_vlp_solve_primal.argtypes = [ctypes.c_int] * 3 + [vp] * 8 + [ctypes.c_int] * 2 + [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int] + [ctypes.c_double] * 4 + [ctypes.c_int, vp, vp, vp]
     lib.bslv_vlp_info_free.argtypes = [vp]
     lib.bslv_vlp_info_free.restype = None
     lib.bslv_vlp_solve_dual2.argtypes = lib.bslv_vlp_solve_primal.argtypes
     check((lib.bslv_vlp_solve_dual2 if dual2 else lib.bslv_vlp_solve_primal)(prob["m"], prob["n"], prob["q"], A.ctypes.data, P.ctypes.data, rt.ctypes.data, arrs[0].ctypes.data, arrs[1].ctypes.data,
                                     ct.ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, int(prob.get("optdir", 1)), cone_kind,
                                     None if g is None else g.ctypes.data, 0 if g is None else g.shape[1], None if cc is None else cc.ctypes.data,
-                                    int(bounded), eps_phase0, eps_phase1, eps_benson_phase1, eps_benson_phase2, batch,
+                                    int(bounded), (1 if alg_phase1 == "dual" else 0) | (2 if preimages else 0), eps_phase0, eps_phase1, eps_benson_phase1, eps_benson_phase2, batch,
                                     ctypes.byref(h), ctypes.byref(st), ctypes.byref(info)))
     q = prob["q"]
     out = dict(status=STATUS.get(st.value, st.value), message=info.message.decode(), lps=info.lps, steps=info.steps, c_dir=info.c_dir)

@@ -228,6 +228,10 @@ typedef struct bslv_vlp_info {
     double *c, *eta, *R, *H, *Y, *Z;   /* malloc'ed: c as written to _c.sol (before the sign change of :844-853); free with bslv_vlp_info_free */
     char message[160];            /* the reference's message when the status is not "optimal" */
 } bslv_vlp_info;
+/* flags: PHASE1_DUAL = "-A dual" (opt->alg_phase1, bslv_main.c:283-296: phase1_dual, bslv_algs.c:1248-1371, instead of
+ * phase1_primal); PREIMAGES = "-s" (opt->solution == PRE_IMG_ON; bslv_vlp_solve_primal only): the phase-2 engine keeps the
+ * pre-images (BSLV_BENSON_PREIMAGES) and the directions of the upper image get theirs (bslv_algs.c:1083-1112) */
+enum { BSLV_VLP_PHASE1_DUAL = 1, BSLV_VLP_PREIMAGES = 2 };
 /* cone_kind 0 default (R^q_+), 1 `gen` generates C, 2 `gen` generates C* (vlp->cone_gen); c_in: q or NULL (vlp->c).
  * vlp_status (sol->status, bslv_main.h:103): 1 infeasible, 2 unbounded, 3 no vertex, 4 optimal, 5 input error.
  * With status 4 *engine_out is the finished phase-2 engine (bslv_benson_poly(engine) is the result; destroy it). */
@@ -235,7 +239,7 @@ int  bslv_vlp_solve_primal(int m, int n, int q, const double *A, const double *P
                            const char *rtype, const double *rlb, const double *rub,
                            const char *ctype, const double *clb, const double *cub,
                            int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
-                           int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
+                           int bounded, int flags, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
                            int batch, bslv_benson **engine_out, int *vlp_status, bslv_vlp_info *info /* may be NULL */);
 /* the same with the DUAL algorithm in phase 2 ("-a dual": phase2_dual, bslv_algs.c:1381-1592, P1(w) LPs that differ in the
  * objective; phases 0 and 1 stay primal).  With status 4 *lower_image_out is a polyhedron whose primal side is the LOWER image
@@ -244,14 +248,8 @@ int  bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
                           const char *rtype, const double *rlb, const double *rub,
                           const char *ctype, const double *clb, const double *cub,
                           int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
-                          int bounded, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
+                          int bounded, int flags, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
                           int batch, bslv_poly **lower_image_out, int *vlp_status, bslv_vlp_info *info /* may be NULL */);
-/* "-A dual" (opt->alg_phase1, bslv_main.c:283-296): phase 1 of the calls that follow on this thread runs the dual variant
- * (phase1_dual, bslv_algs.c:1248-1371) instead of phase1_primal */
-int  bslv_vlp_set_alg_phase1(int dual);
-/* "-s" (opt->solution == PRE_IMG_ON) for the calls of bslv_vlp_solve_primal that follow on this thread: the phase-2 engine keeps
- * the pre-images (BSLV_BENSON_PREIMAGES) and the directions of the upper image get theirs (bslv_algs.c:1083-1112) */
-int  bslv_vlp_set_preimages(int on);
 void bslv_vlp_info_free(bslv_vlp_info *info);
 /* cone_vertenum: prim = the non-redundant generators among gen (dim x n_prim), dual = generators of the dual cone
  * (dim x n_dual); malloc'ed, free with bslv_free.  rc_out 1: the cone has no interior (poly__intl_apprx failed). */
