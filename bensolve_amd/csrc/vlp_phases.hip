@@ -7,6 +7,8 @@
 // M[j*k + i] = component j of generator i (sol->Z, sol->Y, sol->R, sol->H, vlp->gen).
 #include "common.h"
 #include <vector>
+#include <deque>
+#include <unordered_map>
 #include <algorithm>
 #include <cmath>
 
@@ -312,7 +314,8 @@ static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int
     for (int k = 0; k < q; k++) { lo[M + n + k] = -INFINITY; up[M + n + k] = INFINITY; }
     bslv_lpq *lp = nullptr;
     bslv_poly *poly = nullptr;
-    int rc = bslv_lpq_create(&lp, M, N, L.data(), lo.data(), up.data(), cost.data(), 0, 0, batch + 2);
+    const int pool = 3 * batch + 8;      // slot 0: the first optimal basis; the others: tableaux of the LPs whose cuts are still young
+    int rc = bslv_lpq_create(&lp, M, N, L.data(), lo.data(), up.data(), cost.data(), 0, 0, pool);
     if (rc) return rc;
     auto done = [&](int r) { if (lp) bslv_lpq_destroy(lp); if (poly && r) { bslv_poly_destroy(poly); poly = nullptr; } return r; };
     if ((rc = bslv_poly_create(&poly, q, 2 /* upperV2lowerH */, S.c.data()))) return done(rc);
@@ -339,10 +342,16 @@ static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int
     int irc = 0;
     if ((rc = bslv_poly_init(poly, &irc))) return done(rc);
     if (irc) { set_error("phase 2 (dual): initial outer approximation failed (bslv_poly.c:174)"); return done(BSLV_E_STATE); }
-    // PART 2 (:1445-1500), batched
+    // PART 2 (:1445-1500), batched.  Warm starts: a vertex y* of the lower image was created by a cut, i.e. by the optimal y of
+    // an earlier P1(w'); w(y*) is close to w', so that LP's basis (kept in a tableau slot as long as the pool allows, oldest
+    // evicted first, at most 64 generations deep) is the start -- a handful of primal pivots instead of hundreds from the root.
     std::vector<int> idx(batch), ideal(batch), parent(batch), src(batch, 0), dst(batch), stv(batch), itv(batch), rcv(batch), marks;
     std::vector<double> vals((size_t)batch * q), W((size_t)batch * q), Y((size_t)batch * q), obj(batch), cuts;
-    for (int k = 0; k < batch; k++) dst[k] = k + 1;
+    std::vector<int> free_slots, gen(pool, 0);
+    for (int sl = pool - 1; sl >= 1; sl--) free_slots.push_back(sl);
+    std::unordered_map<int, int> facet_slot;
+    std::deque<std::pair<int, int>> young;                                           // (facet, slot), oldest first
+    std::vector<char> is_src(pool, 0);
     for (;;) {
         int cnt = 0;
         if ((rc = bslv_poly_unprocessed2(poly, batch, 0, idx.data(), vals.data(), ideal.data(), parent.data(), &cnt))) return done(rc);
@@ -353,11 +362,27 @@ static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int
         std::vector<int> pts;                                                        // positions of the points of this batch
         for (int k = 0; k < nb; k++) { if (ideal[k]) marks.push_back(idx[k]); else pts.push_back(k); }   // :1456-1459
         const int np = (int)pts.size();
+        std::fill(is_src.begin(), is_src.end(), 0);
         for (int t = 0; t < np; t++) {                                               // w(y*) (:1461-1467)
             const double *v = &vals[(size_t)pts[t] * q];
             double last = 1.0;
             for (int i = 0; i < q - 1; i++) { W[(size_t)t * q + i] = v[i]; last -= v[i] * S.c[i]; }
             W[(size_t)t * q + q - 1] = last;
+            auto it2 = facet_slot.find(parent[pts[t]]);
+            src[t] = (it2 != facet_slot.end() && gen[it2->second] < 64) ? it2->second : 0;
+            is_src[src[t]] = 1;
+        }
+        for (int t = 0; t < np; t++) {
+            while (free_slots.empty()) {                                             // evict the oldest tableau that is not a start of this batch
+                if (young.empty()) { set_error("phase 2 (dual): tableau pool exhausted"); return done(BSLV_E_NOMEM); }
+                auto pr = young.front(); young.pop_front();
+                auto it2 = facet_slot.find(pr.first);
+                if (it2 != facet_slot.end() && it2->second == pr.second) facet_slot.erase(it2);
+                if (is_src[pr.second]) young.emplace_back(-1, pr.second);            // still needed by this batch: comes up again later
+                else free_slots.push_back(pr.second);
+            }
+            dst[t] = free_slots.back(); free_slots.pop_back();
+            gen[dst[t]] = gen[src[t]] + 1;
         }
         if (np > 0) {
             if ((rc = bslv_lpq_solve_batch_obj(lp, np, src.data(), dst.data(), nullptr, nullptr, M + n, q, W.data(), stv.data(), itv.data()))) return done(rc);
@@ -370,16 +395,20 @@ static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int
             if ((rc = bslv_lpq_get_primal(lp, np, dst.data(), M + n, q, Y.data()))) return done(rc);
             if ((rc = bslv_lpq_get_obj(lp, np, dst.data(), obj.data()))) return done(rc);
             cuts.clear();
-            std::vector<int> cut_src;
+            std::vector<int> cut_src, cut_slot;
             for (int t = 0; t < np; t++) {
                 const double opt_val = vals[(size_t)pts[t] * q + q - 1];
-                if (opt_val - obj[t] > eps) { cuts.insert(cuts.end(), &Y[(size_t)t * q], &Y[(size_t)t * q] + q); cut_src.push_back(idx[pts[t]]); }   // :1479-1486
-                else marks.push_back(idx[pts[t]]);                                                                                    // :1488-1497
+                if (opt_val - obj[t] > eps) { cuts.insert(cuts.end(), &Y[(size_t)t * q], &Y[(size_t)t * q] + q); cut_src.push_back(idx[pts[t]]); cut_slot.push_back(dst[t]); }   // :1479-1486
+                else { marks.push_back(idx[pts[t]]); free_slots.push_back(dst[t]); }                                                    // :1488-1497
             }
             const int nc = (int)cut_src.size();
             if (nc > 0) {
+                const int f0 = bslv_poly_ndual(poly);                                // facet ids of the new cuts: f0, f0 + 1, ...
                 if ((rc = bslv_poly_add_cuts(poly, nc, cuts.data(), nullptr, rcv.data()))) return done(rc);
-                for (int k = 0; k < nc; k++) if (rcv[k]) marks.push_back(cut_src[k]);      // nothing was cut off: the vertex stays, processed
+                for (int k = 0; k < nc; k++) {
+                    if (rcv[k]) { marks.push_back(cut_src[k]); free_slots.push_back(cut_slot[k]); }      // nothing was cut off: the vertex stays, processed
+                    else { facet_slot[f0 + k] = cut_slot[k]; young.emplace_back(f0 + k, cut_slot[k]); }
+                }
             }
         }
         if (!marks.empty() && (rc = bslv_poly_mark(poly, (int)marks.size(), marks.data()))) return done(rc);
