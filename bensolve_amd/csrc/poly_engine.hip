@@ -1450,7 +1450,7 @@ template <int NWC>
 __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const unsigned long long *bits, const unsigned long long *rows, unsigned *adj_bits,
                                          int (*queue)[128])
 {
-    const int npairs = nm * (nm - 1) / 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the row intersection of one candidate
     auto sweep = [&](int p) {
         int i, j;
