@@ -127,6 +127,25 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *to
     }
 }
 
+// large arrays of block sums (a new facet with 10^4-10^5 elements has 10^6-10^7 pair blocks; one workgroup walks them in
+// milliseconds): chunks of 1024 sums are scanned by one workgroup each, the chunk totals by k_scan_blocks, and the chunk
+// prefixes added back
+__global__ __launch_bounds__(1024) void k_scan_chunks(Tri *sums, int nb, Tri *aux)
+{
+    __shared__ Tri lds[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    Tri v = i < nb ? sums[i] : Tri{0, 0, 0};
+    Tri tot;
+    Tri ex = block_exscan(v, &tot, lds);
+    if (i < nb) sums[i] = ex;
+    if (threadIdx.x == 0) aux[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void k_scan_add(Tri *sums, int nb, const Tri *aux)
+{
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < nb) sums[i] = tri_add(sums[i], aux[blockIdx.x]);
+}
+
 // ---------------- K1: classify ----------------
 __device__ __forceinline__ signed char classify_one(const PolyView &P, const Hp &hp, int i, unsigned char fl)
 {
@@ -894,6 +913,7 @@ __global__ __launch_bounds__(PB) void k_pair_emit(const int *members, int nm, co
     __shared__ Tri lds[16];
     const PairBlk pb = blks ? blks[blockIdx.x] : pair_block(nm, blockIdx.x);
     unsigned char f = pflag[(size_t)blockIdx.x * PB + threadIdx.x];
+    if (!__syncthreads_or(f)) return;          // (nearly every block of a large facet: no adjacent pair in it)
     Tri t{f, 0, 0};
     Tri tot;
     Tri ex = block_exscan(t, &tot, lds);
@@ -1955,6 +1975,7 @@ struct bslv_poly {
     double tm_launch[4] = {0, 0, 0, 0};      // us: queueing round A, k_emit2, all of round B, waiting for the mailbox   // host wall clock (ms), printed at destroy with BSLV_TIMING
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
+    Tri *bsum2 = nullptr; size_t bsum2cap = 0;       // chunk totals of the two-level scan (k_scan_chunks)
     Tri *totals = nullptr;            // device, 4 entries
     int *counters = nullptr;          // device, 4 ints
     Tri *totals_h = nullptr; int *counters_h = nullptr;   // pinned
@@ -2190,7 +2211,15 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     } else      // enormous local facet sets: sorted-list version
         hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)nbp), dim3(PB), 0, s, h->P, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum);
     const int seq = ++h->mailseq;
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, (int)nbp, h->totals + 2, h->mail_d + 2, (const int *)nullptr, seq);
+    if (nbp <= (1 << 16))
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, (int)nbp, h->totals + 2, h->mail_d + 2, (const int *)nullptr, seq);
+    else {
+        const int nch = (int)((nbp + 1023) / 1024);
+        if ((size_t)nch > h->bsum2cap) { size_t nc = std::max((size_t)nch, h->bsum2cap * 2); if ((rc = grow(&h->bsum2, 0, nc, s))) return rc; h->bsum2cap = nc; }
+        hipLaunchKernelGGL(k_scan_chunks, dim3(nch), dim3(1024), 0, s, h->bsum, (int)nbp, h->bsum2);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum2, nch, h->totals + 2, h->mail_d + 2, (const int *)nullptr, seq);
+        hipLaunchKernelGGL(k_scan_add, dim3(nch), dim3(1024), 0, s, h->bsum, (int)nbp, (const Tri *)h->bsum2);
+    }
     HIP_TRY(hipGetLastError());
     if ((rc = wait_mail(h, 2, seq))) return rc;
     const Tri tp = h->mail_h[2].t;
@@ -2664,7 +2693,7 @@ void bslv_poly_destroy(bslv_poly *h)
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
-    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
