@@ -863,7 +863,50 @@ __global__ __launch_bounds__(PB) void k_build_bits(PolyView P, const int *member
         }
     }
 }
-__global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum)
+// Facet-major member lists of the local bit matrix (large facets): cnt[f] elements carry local facet f, list[off[f] ..] are
+// their positions.  The order inside a list is whatever the atomics give; it is only used for an existence test.
+__global__ __launch_bounds__(PB) void k_fm_count(const unsigned long long *bits, int nm, int W, int *cnt)
+{
+    const long long t = (long long)blockIdx.x * PB + threadIdx.x;
+    if (t >= (long long)W * nm) return;
+    unsigned long long x = bits[t];
+    const int w = (int)(t / nm);
+    while (x) { const int b = __ffsll((long long)x) - 1; x &= x - 1; atomicAdd(&cnt[w * 64 + b], 1); }
+}
+__global__ __launch_bounds__(1024) void k_fm_scan(const int *cnt, int *off, int *cur, int n)
+{
+    __shared__ int s_part[1024];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? cnt[i] : 0;
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int a = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += a;
+            __syncthreads();
+        }
+        const int ex = s_part[threadIdx.x] - v + s_carry;
+        if (i < n) { off[i] = ex; cur[i] = ex; }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(PB) void k_fm_fill(const unsigned long long *bits, int nm, int W, int *cur, int *list)
+{
+    const long long t = (long long)blockIdx.x * PB + threadIdx.x;
+    if (t >= (long long)W * nm) return;
+    unsigned long long x = bits[t];
+    const int w = (int)(t / nm), m = (int)(t % nm);
+    while (x) { const int b = __ffsll((long long)x) - 1; x &= x - 1; list[atomicAdd(&cur[w * 64 + b], 1)] = m; }
+}
+__global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum,
+                                                         const int *fm_cnt, const int *fm_off, const int *fm_list /* NULL: scan all elements */)
 {
     __shared__ Tri lds[16];
     extern __shared__ unsigned long long s_m[];      // W words of row i, then 4 x W words (one M per wave)
@@ -887,6 +930,28 @@ __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned lo
         for (int w = lane; w < W; w += WAVE) Mw[w] = s_m[w] & bits[(size_t)w * nm + cj];
         __builtin_amdgcn_wave_barrier();
         bool found = false;
+        if (fm_list) {
+            // a third element on all mutual facets lies in particular on the mutual facet with the fewest elements: scan that list
+            int bc = 0x7fffffff, bf = -1;
+            for (int w = 0; w < W; w++) if ((Mw[w] >> lane) & 1ull) { const int c = fm_cnt[w * 64 + lane]; if (c < bc) { bc = c; bf = w * 64 + lane; } }
+            for (int o = 32; o > 0; o >>= 1) {
+                const int oc = __shfl_xor(bc, o, WAVE), of = __shfl_xor(bf, o, WAVE);
+                if (oc < bc || (oc == bc && of < bf)) { bc = oc; bf = of; }
+            }
+            const int *Lf = fm_list + fm_off[bf];
+            for (int base = 0; base < bc; base += WAVE) {
+                bool hit = false;
+                if (base + lane < bc) {
+                    const int wv = Lf[base + lane];
+                    if (wv != pb.i && wv != cj) {
+                        hit = true;
+                        for (int w = 0; w < W; w++)
+                            if (Mw[w] & ~bits[(size_t)w * nm + wv]) { hit = false; break; }
+                    }
+                }
+                if (__ballot(hit)) { found = true; break; }
+            }
+        } else
         for (int base = 0; base < nm; base += WAVE) {
             const int wv = base + lane;
             bool hit = false;
@@ -1975,7 +2040,8 @@ struct bslv_poly {
     double tm_launch[4] = {0, 0, 0, 0};      // us: queueing round A, k_emit2, all of round B, waiting for the mailbox   // host wall clock (ms), printed at destroy with BSLV_TIMING
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
-    Tri *bsum2 = nullptr; size_t bsum2cap = 0;       // chunk totals of the two-level scan (k_scan_chunks)
+    Tri *bsum2 = nullptr; size_t bsum2cap = 0;
+    int *fm_cnt = nullptr, *fm_list = nullptr; size_t fmcap = 0, fmlistcap = 0; int fm_min = 4096; long n_fm = 0;      // facet-major member lists of a large new facet (k_fm_*)       // chunk totals of the two-level scan (k_scan_chunks)
     Tri *totals = nullptr;            // device, 4 entries
     int *counters = nullptr;          // device, 4 ints
     Tri *totals_h = nullptr; int *counters_h = nullptr;   // pinned
@@ -2207,7 +2273,22 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
         const int nbm = (nm * LPM + PB - 1) / PB;
         hipLaunchKernelGGL(k_local_ids, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, stamp, h->fstamp, h->flocal, h->nlocal, h->bits);
         hipLaunchKernelGGL(k_build_bits, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, h->flocal, h->bits);
-        hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, h->d, h->bits, nm, W, h->pflag, h->bsum);
+        // large facets: member lists by facet, so that confirming an edge scans one facet's elements instead of all nm
+        const bool fm = nm >= h->fm_min && len_ub <= (1ll << 30) && h->d > 1;
+        if (fm) h->n_fm++;
+        if (fm) {
+            const int nf = W * 64;
+            if ((size_t)(3 * nf) > h->fmcap) { size_t nc = std::max((size_t)(3 * nf), h->fmcap * 2); if ((rc = grow(&h->fm_cnt, 0, nc, s))) return rc; h->fmcap = nc; }
+            if ((size_t)len_ub + 64 > h->fmlistcap) { size_t nc = std::max((size_t)len_ub + 64, h->fmlistcap * 2); if ((rc = grow(&h->fm_list, 0, nc, s))) return rc; h->fmlistcap = nc; }
+            HIP_TRY(hipMemsetAsync(h->fm_cnt, 0, (size_t)nf * sizeof(int), s));
+            const long long nwords = (long long)W * nm;
+            const unsigned nbw = (unsigned)((nwords + PB - 1) / PB);
+            hipLaunchKernelGGL(k_fm_count, dim3(nbw), dim3(PB), 0, s, (const unsigned long long *)h->bits, nm, W, h->fm_cnt);
+            hipLaunchKernelGGL(k_fm_scan, dim3(1), dim3(1024), 0, s, (const int *)h->fm_cnt, h->fm_cnt + nf, h->fm_cnt + 2 * nf, nf);
+            hipLaunchKernelGGL(k_fm_fill, dim3(nbw), dim3(PB), 0, s, (const unsigned long long *)h->bits, nm, W, h->fm_cnt + 2 * nf, h->fm_list);
+        }
+        hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
+                           fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr);
     } else      // enormous local facet sets: sorted-list version
         hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)nbp), dim3(PB), 0, s, h->P, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum);
     const int seq = ++h->mailseq;
@@ -2693,7 +2774,7 @@ void bslv_poly_destroy(bslv_poly *h)
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
-    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->fm_cnt); fr(h->fm_list); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
@@ -2973,13 +3054,14 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 1: h->speculate = value != 0; return 0;
     case 2: h->hot_enabled = value != 0; return 0;
     case 3: h->cross_ub = (int)std::max(0L, value); return 0;
+    case 4: h->fm_min = (int)std::max(2L, value); return 0;           /* facets from this size on confirm edges through the facet-major member lists (4096) */
     default: return BSLV_E_ARG;
     }
 }
 int bslv_poly_path_stats(const bslv_poly *h, long out[6])
 {
     if (!h || !out) return BSLV_E_ARG;
-    out[0] = h->hot_chunks; out[1] = h->n_spec; out[2] = h->n_declined; out[3] = h->n_k2_fallback; out[4] = h->n_single; out[5] = 0;
+    out[0] = h->hot_chunks; out[1] = h->n_spec; out[2] = h->n_declined; out[3] = h->n_k2_fallback; out[4] = h->n_single; out[5] = h->n_fm;
     return 0;
 }
 long bslv_poly_conflict_pairs(const bslv_poly *h) { return h ? h->conf_pairs : 0; }

@@ -99,7 +99,7 @@ class PolyEngine:
     def path_stats(self):
         out = (ctypes.c_long * 6)()
         check(self.lib.bslv_poly_path_stats(self.h, out))
-        return dict(hot_chunks=out[0], speculative=out[1], declined=out[2], prune_fallbacks=out[3], single_cuts=out[4])
+        return dict(hot_chunks=out[0], speculative=out[1], declined=out[2], prune_fallbacks=out[3], single_cuts=out[4], member_list_prunes=out[5])
 
     def init(self):
         rc = ctypes.c_int()

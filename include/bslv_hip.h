@@ -129,10 +129,11 @@ int  bslv_poly_set_batch_mode(bslv_poly *h, int mode);
 long bslv_poly_rounds_run(const bslv_poly *h);
 /* which paths of the single-cut pipeline ran (tests, tuning): out[0] chunks in hot mode, [1] cuts whose round B was
  * queued speculatively, [2] of those declined by the device and rerun, [3] prunes redone by the multi-kernel path,
- * [4] cuts applied one at a time, [5] reserved */
+ * [4] cuts applied one at a time, [5] multi-kernel prunes that confirmed their edges through facet-major member lists */
 int  bslv_poly_path_stats(const bslv_poly *h, long out[6]);
 /* test hook, same switches as the BSLV_* environment variables but at run time: key 0 dynamic LDS bytes of the one-workgroup
- * prune (64 forces the multi-kernel prune), 1 speculative launch on/off, 2 hot mode on/off, 3 CROSS_UB */
+ * prune (64 forces the multi-kernel prune), 1 speculative launch on/off, 2 hot mode on/off, 3 CROSS_UB, 4 size of a new facet
+ * from which the multi-kernel prune builds facet-major member lists (default 4096) */
 int  bslv_poly_debug_set(bslv_poly *h, int key, long value);
 int  bslv_poly_init(bslv_poly *h, int *rc_out);               /* poly__intl_apprx :153 */
 int  bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out); /* poly__get_vrtx :210 */

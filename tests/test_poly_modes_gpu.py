@@ -151,11 +151,13 @@ def test_smid_cut_sequence_matches_oracle_slotwise():
         O.add(y, 0)
     do = O.dump()
     O.close()
-    for force_multi in (False, True):
+    for force_multi in (False, True, "member lists"):
         G = PolyEngine(q, 1, c)
         G.set_batch_mode(0)
         if force_multi:
             G.debug_set(0, 64)
+        if force_multi == "member lists":       # ... and every prune confirms its edges through the facet-major member lists
+            G.debug_set(4, 2)
         for k in range(1, q + 1):
             G.add(Y[k], 0)
         assert G.init() == 0
@@ -166,7 +168,8 @@ def test_smid_cut_sequence_matches_oracle_slotwise():
         paths = G.path_stats()
         G.close()
         assert len(rest) > 1500 and paths["single_cuts"] > 1500
-        assert (paths["prune_fallbacks"] > 1500) == force_multi
+        assert (paths["prune_fallbacks"] > 1500) == bool(force_multi)
+        assert (paths["member_list_prunes"] > 1500) == (force_multi == "member lists")
         for key in ("pu", "pi", "du", "di", "E", "I"):
             assert np.array_equal(do[key], dg[key]), (force_multi, key)
         live = do["pu"].astype(bool)
