@@ -906,7 +906,8 @@ __global__ __launch_bounds__(PB) void k_fm_fill(const unsigned long long *bits, 
     while (x) { const int b = __ffsll((long long)x) - 1; x &= x - 1; list[atomicAdd(&cur[w * 64 + b], 1)] = m; }
 }
 __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum,
-                                                         const int *fm_cnt, const int *fm_off, const int *fm_list /* NULL: scan all elements */)
+                                                         const int *fm_cnt, const int *fm_off, const int *fm_list /* NULL: scan all elements */,
+                                                         int *nzlist /* NULL | blocks with an adjacent pair */, int *nzcount)
 {
     __shared__ Tri lds[16];
     extern __shared__ unsigned long long s_m[];      // W words of row i, then 4 x W words (one M per wave)
@@ -969,7 +970,32 @@ __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned lo
     pflag[(size_t)blockIdx.x * PB + threadIdx.x] = adj ? 1 : 0;
     Tri tot;
     (void)block_exscan(t, &tot, lds);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = tot;
+        if (nzlist && tot.a > 0) nzlist[atomicAdd(nzcount, 1)] = blockIdx.x;
+    }
+}
+
+// emission for large facets: only the pair blocks that hold an adjacent pair (k_pair_flags_bits listed them, in any order:
+// every block writes to its own offset), a fixed grid walking the list
+__global__ __launch_bounds__(PB) void k_pair_emit_list(const int *members, int nm, const int *nzlist, const int *nzcount, const unsigned char *pflag,
+                                                        const Tri *bpre, int2 *E, int ebase, int *EP)
+{
+    __shared__ Tri lds[16];
+    const int n = *nzcount;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int blk = nzlist[k];
+        const PairBlk pb = pair_block(nm, blk);
+        unsigned char f = pflag[(size_t)blk * PB + threadIdx.x];
+        Tri t{f, 0, 0};
+        Tri tot;
+        Tri ex = block_exscan(t, &tot, lds);
+        if (f) {
+            E[ebase + bpre[blk].a + ex.a] = int2{members[pb.i], members[pb.j0 + threadIdx.x]};
+            if (EP) EP[ebase + bpre[blk].a + ex.a] = -1;
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(PB) void k_pair_emit(const int *members, int nm, const PairBlk *blks, const unsigned char *pflag,
@@ -2041,7 +2067,8 @@ struct bslv_poly {
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
     Tri *bsum2 = nullptr; size_t bsum2cap = 0;
-    int *fm_cnt = nullptr, *fm_list = nullptr; size_t fmcap = 0, fmlistcap = 0; int fm_min = 4096; long n_fm = 0;      // facet-major member lists of a large new facet (k_fm_*)       // chunk totals of the two-level scan (k_scan_chunks)
+    int *fm_cnt = nullptr, *fm_list = nullptr; size_t fmcap = 0, fmlistcap = 0; int fm_min = 4096; long n_fm = 0;
+    int *nzlist = nullptr; size_t nzcap = 0;         // pair blocks with an adjacent pair (+ their count behind the list)      // facet-major member lists of a large new facet (k_fm_*)       // chunk totals of the two-level scan (k_scan_chunks)
     Tri *totals = nullptr;            // device, 4 entries
     int *counters = nullptr;          // device, 4 ints
     Tri *totals_h = nullptr; int *counters_h = nullptr;   // pinned
@@ -2268,6 +2295,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     const int W = (int)((std::min<long long>(len_ub, nranks) + 63) / 64);
     if ((size_t)W * nm > h->bitscap) { size_t nc = std::max((size_t)W * nm, h->bitscap * 2); if ((rc = grow(&h->bits, 0, nc, s))) return rc; h->bitscap = nc; }
     const size_t lds_bits = (size_t)W * 5 * sizeof(unsigned long long);
+    bool used_list = false;
     if (lds_bits <= 48 * 1024) {
         HIP_TRY(hipMemsetAsync(h->nlocal, 0, sizeof(int), s));
         const int nbm = (nm * LPM + PB - 1) / PB;
@@ -2281,6 +2309,8 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
             if ((size_t)(3 * nf) > h->fmcap) { size_t nc = std::max((size_t)(3 * nf), h->fmcap * 2); if ((rc = grow(&h->fm_cnt, 0, nc, s))) return rc; h->fmcap = nc; }
             if ((size_t)len_ub + 64 > h->fmlistcap) { size_t nc = std::max((size_t)len_ub + 64, h->fmlistcap * 2); if ((rc = grow(&h->fm_list, 0, nc, s))) return rc; h->fmlistcap = nc; }
             HIP_TRY(hipMemsetAsync(h->fm_cnt, 0, (size_t)nf * sizeof(int), s));
+            if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(hipMalloc(&h->nzlist, (nc + 1) * sizeof(int))); h->nzcap = nc; }
+            HIP_TRY(hipMemsetAsync(h->nzlist + h->nzcap, 0, sizeof(int), s));
             const long long nwords = (long long)W * nm;
             const unsigned nbw = (unsigned)((nwords + PB - 1) / PB);
             hipLaunchKernelGGL(k_fm_count, dim3(nbw), dim3(PB), 0, s, (const unsigned long long *)h->bits, nm, W, h->fm_cnt);
@@ -2288,7 +2318,9 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
             hipLaunchKernelGGL(k_fm_fill, dim3(nbw), dim3(PB), 0, s, (const unsigned long long *)h->bits, nm, W, h->fm_cnt + 2 * nf, h->fm_list);
         }
         hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
-                           fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr);
+                           fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr,
+                           fm ? h->nzlist : (int *)nullptr, fm ? h->nzlist + h->nzcap : (int *)nullptr);
+        used_list = fm;
     } else      // enormous local facet sets: sorted-list version
         hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)nbp), dim3(PB), 0, s, h->P, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum);
     const int seq = ++h->mailseq;
@@ -2307,6 +2339,10 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     if (tp.a > 0) {
         if ((long long)h->ne + tp.a > 0x3FFFFF00ll) { set_error("polyhedron too large: more than 2^30 edges"); return BSLV_E_CAPACITY; }
         if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
+        if (used_list)
+            hipLaunchKernelGGL(k_pair_emit_list, dim3(4096), dim3(PB), 0, s, h->members, nm, (const int *)h->nzlist, (const int *)(h->nzlist + h->nzcap), (const unsigned char *)h->pflag,
+                               (const Tri *)h->bsum, h->E[h->ecur], h->ne, h->EP[h->ecur]);
+        else
         hipLaunchKernelGGL(k_pair_emit, dim3((unsigned)nbp), dim3(PB), 0, s, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum,
                            h->E[h->ecur], h->ne, h->EP[h->ecur]);
         HIP_TRY(hipGetLastError());
@@ -2774,7 +2810,7 @@ void bslv_poly_destroy(bslv_poly *h)
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
-    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->fm_cnt); fr(h->fm_list); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
+    fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->fm_cnt); fr(h->fm_list); fr(h->nzlist); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
