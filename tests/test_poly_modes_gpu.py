@@ -186,3 +186,34 @@ def test_smid_benson_steps_identical_in_all_modes():
     for name in ("conservative", "fallback_prune"):
         for key in ("pu", "pi", "ps", "X", "du", "di", "Y", "E", "I"):
             assert np.array_equal(dumps[name][key], dumps["default"][key]), (name, key)
+
+
+def test_large_facets_member_list_prune_equals_full_scan():
+    """S-degenerate at full size, first steps: new facets of 10^4-10^5 elements go through the multi-kernel prune, which
+    confirms edges against the members of the smallest mutual facet and emits only the pair blocks that hold an edge.  The
+    same steps with that path switched off (every candidate checked against all elements, every block emitted): the same
+    polyhedron bit for bit."""
+    import hashlib
+    from bensolve_amd import synth
+    from bensolve_amd.benson import BensonEngine
+    prob = synth.CONFIGS["S-degenerate"]()
+    out = {}
+    for name, fm_min in (("member lists", 4096), ("full scan", 1 << 30)):
+        eng = BensonEngine(prob, eps=1e-7, pool_slots=4 * 64 + 64)
+        eng.poly_call("debug_set", 4, fm_min)
+        assert eng.start() == 0
+        for _ in range(4):
+            nl, nt = eng.collect(64, 0, 1)
+            rec, piv, ls = eng.solve_local(nl)
+            assert np.all(rec[:, 1] == 4)
+            eng.apply(rec)
+        d = eng.poly_dump()
+        paths = eng.poly_call("path_stats")
+        eng.close()
+        h = hashlib.sha256()
+        for key in ("pu", "pi", "du", "di", "X", "Y", "E", "I"):
+            h.update(np.ascontiguousarray(d[key]).tobytes())
+        out[name] = (h.hexdigest(), int(d["pu"].sum()), len(d["E"]), paths)
+    assert out["member lists"][3]["member_list_prunes"] > 20 and out["full scan"][3]["member_list_prunes"] == 0, out
+    assert out["member lists"][1] > 50000
+    assert out["member lists"][:3] == out["full scan"][:3], out
