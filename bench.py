@@ -32,8 +32,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed outer iterations (default 8; S-degenerate: 3, its polyhedron outgrows 32-bit indices after ~6)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed outer iterations before them (default 2; S-degenerate: 0)")
     ap.add_argument("--workload", default="S-mid")
     ap.add_argument("--batch", type=int, default=0, help="LPs per GPU per step (default by workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -64,6 +64,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
+    if args.steps is None:
+        args.steps = 3 if args.workload == "S-degenerate" else 8
+    if args.warmup is None:
+        args.warmup = 0 if args.workload == "S-degenerate" else 2
     defaults = {"S-small": (2048, 20000), "S-mid": (2048, 800), "S-degenerate": (64, 4)}
     B = args.batch or defaults.get(args.workload, (256, 50))[0]
     cpu_lps = args.cpu_lps or defaults.get(args.workload, (256, 50))[1]
