@@ -202,7 +202,7 @@ def test_large_facets_member_list_prune_equals_full_scan():
         eng = BensonEngine(prob, eps=1e-7, pool_slots=4 * 64 + 64)
         eng.poly_call("debug_set", 4, fm_min)
         assert eng.start() == 0
-        for _ in range(4):
+        for _ in range(5):                  # (the fifth step brings facets of ~10^5 elements: a row-tiled variant of the pair kernel first went wrong there)
             nl, nt = eng.collect(64, 0, 1)
             rec, piv, ls = eng.solve_local(nl)
             assert np.all(rec[:, 1] == 4)
@@ -215,5 +215,5 @@ def test_large_facets_member_list_prune_equals_full_scan():
             h.update(np.ascontiguousarray(d[key]).tobytes())
         out[name] = (h.hexdigest(), int(d["pu"].sum()), len(d["E"]), paths)
     assert out["member lists"][3]["member_list_prunes"] > 20 and out["full scan"][3]["member_list_prunes"] == 0, out
-    assert out["member lists"][1] > 50000
+    assert out["member lists"][1] > 500000
     assert out["member lists"][:3] == out["full scan"][:3], out
