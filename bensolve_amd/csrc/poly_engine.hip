@@ -976,6 +976,90 @@ __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned lo
     }
 }
 
+// The same for large facets, PTI rows per workgroup: the rows' words and a window of PB + PTI - 1 columns are staged in LDS once and
+// serve PTI x PB pairs.  Row i of the tile works on columns i + 1 + PB c + t, i.e. on window position r + t.  pflag / bsum are
+// indexed by the same virtual block id (row i, chunk c) as k_pair_flags_bits uses, so emission and edge order do not change.
+// Grid: x = chunk, y = row group -- which also keeps the launch inside the 2^32 work-items per grid dimension that a
+// one-dimensional grid of pair blocks exceeds from ~92 700 elements on (the runtime wraps such a grid without an error).
+constexpr int PTI = 8;
+__global__ __launch_bounds__(PB) void k_pair_flags_tiled(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum,
+                                                          const int *fm_cnt, const int *fm_off, const int *fm_list /* NULL: scan all elements */,
+                                                          int *nzlist, int *nzcount)
+{
+    extern __shared__ unsigned long long s_t[];       // PTI x W row words | W x (PB + PTI) column words | 4 x W (one M per wave)
+    const int i0 = blockIdx.y * PTI, c = blockIdx.x;
+    const int jbase = i0 + 1 + c * PB;
+    if (i0 >= nm - 1 || jbase >= nm) return;
+    const int CW = PB + PTI;
+    unsigned long long *rowsw = s_t, *colsw = s_t + (size_t)PTI * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long *Mw = colsw + (size_t)W * CW + (size_t)wave * W;
+    for (int x = threadIdx.x; x < PTI * W; x += PB) { const int r = x / W, w = x % W, i = i0 + r; rowsw[x] = i < nm ? bits[(size_t)w * nm + i] : 0ull; }
+    for (int x = threadIdx.x; x < W * CW; x += PB) { const int w = x / CW, k = x % CW, j = jbase + k; colsw[x] = j < nm ? bits[(size_t)w * nm + j] : 0ull; }
+    __syncthreads();
+    const long long L1 = nm - 1, GL = pair_G(L1);
+    for (int r = 0; r < PTI; r++) {
+        const int i = i0 + r, j0 = i + 1 + c * PB;
+        if (i >= nm - 1 || j0 >= nm) break;                       // (uniform: later rows have fewer columns)
+        const unsigned long long *s_m = rowsw + (size_t)r * W;
+        const int j = j0 + threadIdx.x, k = r + threadIdx.x;
+        int nmut = 0;
+        if (j < nm)
+            for (int w = 0; w < W; w++) nmut += __popcll(s_m[w] & colsw[(size_t)w * CW + k]);
+        bool cand = (j < nm) && ((d == 1) || (nmut >= d - 1));        // edge_test, bslv_poly.c:482-485
+        bool adj = cand;
+        unsigned long long todo = __ballot(cand && d > 1);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int cj = j0 + (threadIdx.x - lane) + src;
+            for (int w = lane; w < W; w += WAVE) Mw[w] = s_m[w] & bits[(size_t)w * nm + cj];
+            __builtin_amdgcn_wave_barrier();
+            bool found = false;
+            if (fm_list) {
+                int bc = 0x7fffffff, bf = -1;
+                for (int w = 0; w < W; w++) if ((Mw[w] >> lane) & 1ull) { const int cc = fm_cnt[w * 64 + lane]; if (cc < bc) { bc = cc; bf = w * 64 + lane; } }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int oc = __shfl_xor(bc, o, WAVE), of = __shfl_xor(bf, o, WAVE);
+                    if (oc < bc || (oc == bc && of < bf)) { bc = oc; bf = of; }
+                }
+                const int *Lf = fm_list + fm_off[bf];
+                for (int base = 0; base < bc; base += WAVE) {
+                    bool hit = false;
+                    if (base + lane < bc) {
+                        const int wv = Lf[base + lane];
+                        if (wv != i && wv != cj) {
+                            hit = true;
+                            for (int w = 0; w < W; w++)
+                                if (Mw[w] & ~bits[(size_t)w * nm + wv]) { hit = false; break; }
+                        }
+                    }
+                    if (__ballot(hit)) { found = true; break; }
+                }
+            } else
+            for (int base = 0; base < nm; base += WAVE) {
+                const int wv = base + lane;
+                bool hit = false;
+                if (wv < nm && wv != i && wv != cj) {
+                    hit = true;
+                    for (int w = 0; w < W; w++)
+                        if (Mw[w] & ~bits[(size_t)w * nm + wv]) { hit = false; break; }
+                }
+                if (__ballot(hit)) { found = true; break; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == src) adj = !found;
+        }
+        const long long vb = GL - pair_G(L1 - i) + c;           // virtual block (row i, chunk c), as pair_block enumerates them
+        pflag[(size_t)vb * PB + threadIdx.x] = adj ? 1 : 0;
+        const int cnt = __syncthreads_count(adj);
+        if (threadIdx.x == 0) {
+            bsum[vb] = Tri{cnt, 0, 0};
+            if (nzlist && cnt > 0) nzlist[atomicAdd(nzcount, 1)] = (int)vb;
+        }
+    }
+}
+
 // emission for large facets: only the pair blocks that hold an adjacent pair (k_pair_flags_bits listed them, in any order:
 // every block writes to its own offset), a fixed grid walking the list
 __global__ __launch_bounds__(PB) void k_pair_emit_list(const int *members, int nm, const int *nzlist, const int *nzcount, const unsigned char *pflag,
@@ -2067,7 +2151,7 @@ struct bslv_poly {
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
     Tri *bsum2 = nullptr; size_t bsum2cap = 0;
-    int *fm_cnt = nullptr, *fm_list = nullptr; size_t fmcap = 0, fmlistcap = 0; int fm_min = 4096; long n_fm = 0;
+    int *fm_cnt = nullptr, *fm_list = nullptr; size_t fmcap = 0, fmlistcap = 0; int fm_min = 4096; long n_fm = 0; bool member_lists = true;
     int *nzlist = nullptr; size_t nzcap = 0;         // pair blocks with an adjacent pair (+ their count behind the list)      // facet-major member lists of a large new facet (k_fm_*)       // chunk totals of the two-level scan (k_scan_chunks)
     Tri *totals = nullptr;            // device, 4 entries
     int *counters = nullptr;          // device, 4 ints
@@ -2301,28 +2385,43 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
         const int nbm = (nm * LPM + PB - 1) / PB;
         hipLaunchKernelGGL(k_local_ids, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, stamp, h->fstamp, h->flocal, h->nlocal, h->bits);
         hipLaunchKernelGGL(k_build_bits, dim3(nbm), dim3(PB), 0, s, h->P, h->members, nm, W, h->flocal, h->bits);
-        // large facets: member lists by facet, so that confirming an edge scans one facet's elements instead of all nm
-        const bool fm = nm >= h->fm_min && len_ub <= (1ll << 30) && h->d > 1;
-        if (fm) h->n_fm++;
+        // large facets: the row-tiled pair kernel (2-D grid), the list of pair blocks that hold an edge, and member lists by
+        // facet, so that confirming an edge scans one facet's elements instead of all nm
+        const size_t lds_tiled = ((size_t)PTI * W + (size_t)W * (PB + PTI) + 4 * (size_t)W) * sizeof(unsigned long long);
+        const int ngroups = (nm - 1 + PTI - 1) / PTI;
+        const bool tiled = nm >= h->fm_min && h->d > 1 && lds_tiled <= 48 * 1024 && ngroups <= 65535;
+        const bool fm = tiled && h->member_lists && len_ub <= (1ll << 30);
+        if (tiled) {
+            if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(hipMalloc(&h->nzlist, (nc + 1) * sizeof(int))); h->nzcap = nc; }
+            HIP_TRY(hipMemsetAsync(h->nzlist + h->nzcap, 0, sizeof(int), s));
+        }
         if (fm) {
+            h->n_fm++;
             const int nf = W * 64;
             if ((size_t)(3 * nf) > h->fmcap) { size_t nc = std::max((size_t)(3 * nf), h->fmcap * 2); if ((rc = grow(&h->fm_cnt, 0, nc, s))) return rc; h->fmcap = nc; }
             if ((size_t)len_ub + 64 > h->fmlistcap) { size_t nc = std::max((size_t)len_ub + 64, h->fmlistcap * 2); if ((rc = grow(&h->fm_list, 0, nc, s))) return rc; h->fmlistcap = nc; }
             HIP_TRY(hipMemsetAsync(h->fm_cnt, 0, (size_t)nf * sizeof(int), s));
-            if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(hipMalloc(&h->nzlist, (nc + 1) * sizeof(int))); h->nzcap = nc; }
-            HIP_TRY(hipMemsetAsync(h->nzlist + h->nzcap, 0, sizeof(int), s));
             const long long nwords = (long long)W * nm;
             const unsigned nbw = (unsigned)((nwords + PB - 1) / PB);
             hipLaunchKernelGGL(k_fm_count, dim3(nbw), dim3(PB), 0, s, (const unsigned long long *)h->bits, nm, W, h->fm_cnt);
             hipLaunchKernelGGL(k_fm_scan, dim3(1), dim3(1024), 0, s, (const int *)h->fm_cnt, h->fm_cnt + nf, h->fm_cnt + 2 * nf, nf);
             hipLaunchKernelGGL(k_fm_fill, dim3(nbw), dim3(PB), 0, s, (const unsigned long long *)h->bits, nm, W, h->fm_cnt + 2 * nf, h->fm_list);
         }
-        hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
-                           fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr,
-                           fm ? h->nzlist : (int *)nullptr, fm ? h->nzlist + h->nzcap : (int *)nullptr);
-        used_list = fm;
-    } else      // enormous local facet sets: sorted-list version
+        if (tiled)
+            hipLaunchKernelGGL(k_pair_flags_tiled, dim3((unsigned)((nm - 1 + PB - 1) / PB), (unsigned)ngroups), dim3(PB), lds_tiled, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
+                               fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr,
+                               h->nzlist, h->nzlist + h->nzcap);
+        else {
+            // one-dimensional grid of pair blocks: at most 2^32 work-items (the runtime wraps a larger grid silently)
+            if ((long long)nbp * PB >= (1ll << 32)) { set_error("new facet has too many elements (%d) for the one-dimensional pair launch", nm); return BSLV_E_CAPACITY; }
+            hipLaunchKernelGGL(k_pair_flags_bits, dim3((unsigned)nbp), dim3(PB), lds_bits, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
+                               (const int *)nullptr, (const int *)nullptr, (const int *)nullptr, (int *)nullptr, (int *)nullptr);
+        }
+        used_list = tiled;
+    } else {    // enormous local facet sets: sorted-list version
+        if ((long long)nbp * PB >= (1ll << 32)) { set_error("new facet has too many elements (%d) for the one-dimensional pair launch", nm); return BSLV_E_CAPACITY; }
         hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)nbp), dim3(PB), 0, s, h->P, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum);
+    }
     const int seq = ++h->mailseq;
     if (nbp <= (1 << 16))
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, h->bsum, (int)nbp, h->totals + 2, h->mail_d + 2, (const int *)nullptr, seq);
@@ -3090,7 +3189,8 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 1: h->speculate = value != 0; return 0;
     case 2: h->hot_enabled = value != 0; return 0;
     case 3: h->cross_ub = (int)std::max(0L, value); return 0;
-    case 4: h->fm_min = (int)std::max(2L, value); return 0;           /* facets from this size on confirm edges through the facet-major member lists (4096) */
+    case 4: h->fm_min = (int)std::max(2L, value); return 0;
+    case 5: h->member_lists = value != 0; return 0;                     /* edges of large facets confirmed through member lists (1) or against all elements (0) */           /* facets from this size on confirm edges through the facet-major member lists (4096) */
     default: return BSLV_E_ARG;
     }
 }
