@@ -38,7 +38,11 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="LPs per GPU per step (default by workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="N=1 only: overlap the LPs of batch k with the cuts of batch k-1 (measured slower on S-mid: the one-batch lag costs more cuts per LP than the overlap saves)")
-    ap.add_argument("--policy", type=int, default=0, help="batch selection: 1 newest first, 2 spread (default by workload)")
+    ap.add_argument("--policy", type=int, default=0, help="batch selection: 1 newest first, 2 spread, 3 newest first with at most --sib-cap children of one cut (default by workload)")
+    ap.add_argument("--sib-cap", type=int, default=1)
+    ap.add_argument("--sib-window", type=int, default=8)
+    ap.add_argument("--pool", type=int, default=0, help="tableau slots (default 4*batch+64)")
+    ap.add_argument("--no-pair", action="store_true", help="skip the S-small whole-run GPU/CPU pair of cpu_baseline")
     ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
     args = ap.parse_args()
 
@@ -68,16 +72,22 @@ def main():
         args.steps = 3 if args.workload == "S-degenerate" else 8
     if args.warmup is None:
         args.warmup = 0 if args.workload == "S-degenerate" else 2
-    defaults = {"S-small": (2048, 20000), "S-mid": (2048, 800), "S-degenerate": (64, 4)}
-    B = args.batch or defaults.get(args.workload, (256, 50))[0]
-    cpu_lps = args.cpu_lps or defaults.get(args.workload, (256, 50))[1]
+    defaults = {"S-small": 2048, "S-mid": 2048, "S-degenerate": 64}
+    B = args.batch or defaults.get(args.workload, 256)
+    # CPU sample: (warm-up, rated) LPs in the reference's vertex order, then newest first
+    cpu_plan = {"S-small": (1000, 8000, 1000, 8000), "S-mid": (100, 200, 200, 1500), "S-degenerate": (2, 2, 2, 2)}.get(args.workload, (50, 200, 50, 200))
+    if args.cpu_lps:
+        cpu_plan = (cpu_plan[0], args.cpu_lps, cpu_plan[2], args.cpu_lps)
     prob = synth.CONFIGS[args.workload]()
     m, n, q = prob["m"], prob["n"], prob["q"]
     r = q
-    eng = BensonEngine(prob, eps=1e-7, pool_slots=4 * B + 64)
+    pool_slots = args.pool or 4 * B + 64
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=pool_slots)
     slot_bytes = eng.lp_call("slot_bytes")
     if args.policy:
         eng.set_policy(args.policy)
+        if args.policy == 3:
+            eng.set_sibling_rule(args.sib_cap, args.sib_window)
     st = eng.start()
     if st != 0:
         raise SystemExit("phase 2 start failed: vlp status %d" % st)
@@ -128,6 +138,7 @@ def main():
     eng.lp_call("set_profile", True)
     phase_ms[:] = [0.0, 0.0, 0.0]
     rounds0 = eng.poly_call("rounds_run")
+    ps0 = eng.poly_call("path_stats")
     nv0 = eng.poly_call("counts")["new_vertices"]
     pt0 = eng.poly_call("counts")["pair_tests"]
     lps = cuts = pivots = lockstep = redundant = confirmed = passes = 0
@@ -191,35 +202,81 @@ def main():
                 "per_pivot_equivalent_GBps": round(per_pivot_equiv, 1),
                 "note": "per_pivot_equivalent = what one read+write of the tableau PER PIVOT (SURVEY 8d K3, the reference's GLPK-style update) would need to move in the same time"}
 
+    # second figure of merit: the cut phase (bslv_poly's half of the path).  Not HBM-bound (integer / LDS /
+    # latency): reported as time per cut, cuts per pass over the polyhedron, and pair tests per second next to the
+    # reference's own bslv_poly.c on one core (6.9e6/s at q=5, N=1000).
+    cut_ms = phase_ms[2]
+    passes_poly = eng.poly_call("rounds_run") - rounds0
+    ps = eng.poly_call("path_stats")
+    roofline_cuts = {"bound": "latency/integer (not hbm)", "kernels": "k_flags2+k_emit2+k2_fused per single cut; k_classify_batch_t+k_edge_emit_m+k_pair_flags_m per multi-cut pass",
+                     "cuts_applied": cuts, "cuts_per_step": round(cuts / max(args.steps, 1), 1),
+                     "us_per_cut": round(cut_ms * 1e3 / max(cuts, 1), 2) if world == 1 and pipe is None else None,
+                     "passes_over_polyhedron": passes_poly, "cuts_per_pass": round(cuts / max(passes_poly, 1), 2),
+                     "single_cut_pipeline_cuts": ps["single_cuts"] - ps0["single_cuts"], "hot_chunks": ps["hot_chunks"] - ps0["hot_chunks"],
+                     "pair_tests_per_sec": round(pair_tests / dt, 1), "reference_pair_tests_per_sec_1core": 6.9e6,
+                     "note": "a single cut runs on ~10^2 workgroups for ~50 us (dependent chain of 3 launches); a multi-cut pass applies all independent cuts of a batch in one sweep"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_api
-        t1 = time.perf_counter()
-        rc, fp, cst = oracle_api.benson_phase2_primal(prob, eps=1e-7, max_lps=cpu_lps)
+        # same stage on both sides: the CPU oracle first works through `warm` LPs untimed-by-us (its cold solve and the first,
+        # far-apart vertices), then the LPs behind the warm-up are rated -- (a) in the reference's own vertex order (lowest slot
+        # first, poly__get_vrtx) and (b) newest first, the order the batched driver uses (consecutive vertices are neighbours:
+        # few pivots per warm-started LP).  In the sequential loop every LP is useful (one cut or one confirmation).
+        warm_a, n_a, warm_b, n_b = cpu_plan
+        rc, fp, ca = oracle_api.benson_phase2_primal(prob, eps=1e-7, max_lps=warm_a + n_a, order=0, warm_lps=warm_a)
         fp.close()
-        cpu = {"value": round(cst.lps / cst.secs_total, 3), "unit": "LPs/s", "cores": 1, "kind": "port",
-               "sample": "oracle/benson_cpu.c (sequential phase2_primal loop, warm-started dense dual simplex + CPU double "
-                         "description; GLPK is not installed so the reference's LP half cannot run), first %d LPs of %s from "
-                         "a cold start, %.1f s, %d pivots; vertices/s %.1f" % (cst.lps, args.workload, cst.secs_total, cst.pivots,
-                                                                              cst.new_vertices / cst.secs_total),
-               "pivots_per_lp": round(cst.pivots / max(cst.lps, 1), 1)}
+        rc, fp, cb = oracle_api.benson_phase2_primal(prob, eps=1e-7, max_lps=warm_b + n_b, order=1, warm_lps=warm_b)
+        fp.close()
+
+        def rate(c):
+            w = c.warm_lps if c.warm_lps else 0
+            secs = c.secs_total - (c.warm_secs if w else 0.0)
+            lp = c.lps - w
+            return lp / max(secs, 1e-9), (c.pivots - (c.warm_pivots if w else 0)) / max(lp, 1), lp, secs, (c.new_vertices - (c.warm_new_vertices if w else 0)) / max(secs, 1e-9)
+        ra, rb = rate(ca), rate(cb)
+        cpu = {"value": round(ra[0], 3), "unit": "LPs/s", "cores": 1, "kind": "port",
+               "sample": "oracle/benson_cpu.c (sequential phase2_primal loop: one vertex -> one warm-started dense dual simplex LP -> one cut; "
+                         "GLPK is not installed, so the reference's own LP half cannot run), %s, reference vertex order (lowest slot first), "
+                         "%d LPs after a warm-up of %d LPs, %.1f s" % (args.workload, ra[2], ca.warm_lps, ra[3]),
+               "pivots_per_lp": round(ra[1], 1), "vertices_per_sec": round(ra[4], 1),
+               "newest_first": {"value": round(rb[0], 3), "pivots_per_lp": round(rb[1], 1), "lps": rb[2], "warmup_lps": cb.warm_lps, "secs": round(rb[3], 2),
+                                "vertices_per_sec": round(rb[4], 1),
+                                "note": "same oracle, vertices taken newest first as the batched driver does: the best sequential order for warm starts"},
+               "every_lp_useful": True}
+        if not args.no_pair and args.workload != "S-small":
+            # like-for-like pair: S-small to termination on both sides (same problem, same eps, whole phase 2)
+            sp = synth.CONFIGS["S-small"]()
+            e2 = BensonEngine(sp, eps=1e-7, pool_slots=4 * 2048 + 64)
+            e2.start()
+            torch.cuda.synchronize(); tg = time.perf_counter()
+            e2.run(2048)
+            torch.cuda.synchronize(); tg = time.perf_counter() - tg
+            tot = e2.totals()
+            e2.close()
+            rc, fp, cs = oracle_api.benson_phase2_primal(sp, eps=1e-7)
+            fp.close()
+            cpu["whole_run_pair"] = {"workload": "S-small (q=3, n=100, m=200) phase 2 to termination", "gpu_secs": round(tg, 4), "gpu_lps": tot["lps"],
+                                     "cpu_secs": round(cs.secs_total, 4), "cpu_lps": cs.lps, "speedup_time_to_termination": round(cs.secs_total / max(tg, 1e-9), 2)}
 
     if rank == 0:
         out = {
             "metric": "scalar LPs/sec (Benson phase 2, batched P2(v) solves incl. cut application), synthetic VLP q=%d n=%d m=%d" % (q, n, m),
-            "value": round(lps / dt, 2), "unit": "LPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(lps / dt, 2), "unit": "LPs/s",
+            "useful_lps_per_sec": round((cuts + confirmed) / dt, 2), "lps_redundant_frac": round(1.0 - (cuts + confirmed) / max(lps, 1), 4),
+            "useful_note": "useful = LPs whose outcome changed the state (cut applied or vertex confirmed); the rest returned a cut that an earlier LP of the same batch had already delivered.  The reference's sequential loop solves only useful LPs (bslv_algs.c:1030-1080): compare useful_lps_per_sec with cpu_baseline.value", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s (q=%d, n=%d, m=%d dense covering VLP, seed per SURVEY 8d)" % (args.workload, q, n, m),
                        "lp_rows_cols": [dims["M"], dims["N"]], "rows_folded_by_presolve": dims["rows_folded"], "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "vertex batch sharded over %d GPU(s), one all_gather of cut records per step" % world,
                        "lp_poly_overlap": pipe is not None,
-                       "tableau_slot_bytes": slot_bytes, "pool_slots": 4 * B + 64, "ramp_steps_untimed": ramp_steps},
+                       "tableau_slot_bytes": slot_bytes, "pool_slots": pool_slots, "batch_policy": args.policy or 1, "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
             "live_vertices": live, "poly_rounds": eng.poly_call("rounds_run") - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": {"collect": round(phase_ms[0] / args.steps, 2), "lp": round(phase_ms[1] / args.steps, 2), "cuts": round(phase_ms[2] / args.steps, 2)}, "update_kernel_ms_rank0": round(upd_ms, 2),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_cuts": roofline_cuts, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     eng.close()

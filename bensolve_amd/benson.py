@@ -104,6 +104,16 @@ class BensonEngine:
     def set_policy(self, policy):
         check(self.lib.bslv_benson_set_policy(self.h, int(policy)))
 
+    def set_sibling_rule(self, cap, window):
+        self.lib.bslv_benson_set_sibling_rule.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        check(self.lib.bslv_benson_set_sibling_rule(self.h, int(cap), int(window)))
+
+    def pool_stats(self):
+        out = (ctypes.c_long * 4)()
+        self.lib.bslv_benson_pool_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        check(self.lib.bslv_benson_pool_stats(self.h, out))
+        return dict(zip(("free", "resident", "held", "pool"), list(out)))
+
     def start(self):
         st = ctypes.c_int()
         check(self.lib.bslv_benson_start(self.h, ctypes.byref(st)))

@@ -59,7 +59,8 @@ struct bslv_benson {
     int mark_at_collect = 0;                          // pipelined mode: batch members get the sltn mark when collected
     int rank = 0, world = 1;
     int unprocessed_left = 0;
-    int policy = 1;                                   // 1: newest vertices first (depth first), 2: spread over the whole queue
+    int policy = 1;                                   // 1: newest vertices first (depth first), 2: spread over the whole queue, 3: newest first, few siblings
+    int sib_cap = 1, sib_window = 8;                  // policy 3: children of one cut per batch; depth of the window in batches
     std::vector<double> slot_src;                     // per slot: vertex its LP was solved for (pool_slots x q)
     std::vector<char> slot_valid;
     std::vector<int> slot_gen;                        // generations of warm starts between the root tableau and this slot
@@ -257,21 +258,46 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
     h->rank = rank; h->world = world;
     int rc, cnt = 0;
     for (;;) {
-        if ((rc = bslv_poly_unprocessed2(h->poly, 0, h->policy, nullptr, nullptr, nullptr, nullptr, &cnt))) return rc;
-        int nb = std::min(cnt, max_batch);
+        const int pol = h->policy == 3 ? 1 : h->policy;
+        if ((rc = bslv_poly_unprocessed2(h->poly, 0, pol, nullptr, nullptr, nullptr, nullptr, &cnt))) return rc;
+        // policy 3 looks at a window of the newest unprocessed elements several batches deep and takes at most `sib_cap`
+        // children of one cut from it (see bslv_benson_set_policy)
+        const long long want = h->policy == 3 ? (long long)max_batch * h->sib_window : max_batch;
+        int nb = (int)std::min<long long>(cnt, want);
         std::vector<int> idx(nb), ideal(nb), parent(nb);
         std::vector<double> val((size_t)nb * q);
-        if (nb && (rc = bslv_poly_unprocessed2(h->poly, nb, h->policy, idx.data(), val.data(), ideal.data(), parent.data(), &cnt))) return rc;
+        if (nb && (rc = bslv_poly_unprocessed2(h->poly, nb, pol, idx.data(), val.data(), ideal.data(), parent.data(), &cnt))) return rc;
         std::vector<int> dirs;
         B.b_idx.clear(); B.b_val.clear(); B.b_parent.clear();
-        for (int k = 0; k < nb; k++) {
-            if (ideal[k]) { dirs.push_back(idx[k]); continue; }
-            B.b_idx.push_back(idx[k]);
-            B.b_parent.push_back(parent[k]);
-            B.b_val.insert(B.b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
+        int taken = 0;
+        if (h->policy == 3) {
+            // newest first; the chosen elements are handed on in ascending slot order, as with the other policies
+            std::unordered_map<int, int> per_parent;
+            std::vector<int> pick;
+            for (int k = nb - 1; k >= 0; k--) {
+                if (ideal[k]) { dirs.push_back(idx[k]); taken++; continue; }
+                if ((int)pick.size() >= max_batch) continue;
+                if (parent[k] >= 0 && ++per_parent[parent[k]] > h->sib_cap) continue;
+                pick.push_back(k);
+            }
+            std::reverse(pick.begin(), pick.end());
+            for (int k : pick) {
+                B.b_idx.push_back(idx[k]);
+                B.b_parent.push_back(parent[k]);
+                B.b_val.insert(B.b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
+            }
+            taken += (int)pick.size();
+        } else {
+            for (int k = 0; k < nb; k++) {
+                if (ideal[k]) { dirs.push_back(idx[k]); continue; }
+                B.b_idx.push_back(idx[k]);
+                B.b_parent.push_back(parent[k]);
+                B.b_val.insert(B.b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
+            }
+            taken = nb;
         }
         if (!dirs.empty() && (rc = bslv_poly_mark(h->poly, (int)dirs.size(), dirs.data()))) return rc;
-        h->unprocessed_left = cnt - nb;
+        h->unprocessed_left = cnt - taken;
         if (!B.b_idx.empty() || dirs.empty()) break;     // only directions in this window: look again
     }
     const int nb = (int)B.b_idx.size();
@@ -309,6 +335,9 @@ static int take_slot(bslv_benson *h)      // caller holds slot_mu
         while (want-- > 0 && !h->parents.empty()) {
             auto pr = h->parents.front();
             h->parents.pop_front();
+            // (-2, s): a slot that was evicted while it still served as a warm-start source of a batch (solve_local re-queues
+            // it under this key); nothing refers to it any more, so it goes back to the free list unconditionally
+            if (pr.first == -2) { h->free_slots.push_back(pr.second); continue; }
             auto it = h->facet_slot.find(pr.first);
             if (it != h->facet_slot.end() && it->second == pr.second) { h->facet_slot.erase(it); h->free_slots.push_back(pr.second); }
         }
@@ -583,8 +612,31 @@ int bslv_benson_set_pipelined(bslv_benson *h, int on)
 }
 int bslv_benson_set_policy(bslv_benson *h, int policy)
 {
-    if (!h || policy < 1 || policy > 2) return BSLV_E_ARG;
+    if (!h || policy < 1 || policy > 3) return BSLV_E_ARG;
     h->policy = policy;
+    return 0;
+}
+int bslv_benson_set_sibling_rule(bslv_benson *h, int cap, int window)
+{
+    if (!h || cap < 1 || window < 1) return BSLV_E_ARG;
+    h->sib_cap = cap; h->sib_window = window;
+    return 0;
+}
+// slots of the tableau pool: [0] free, [1] resident parents (warm-start sources), [2] held by the batch contexts, [3] pool size.
+// free + resident + held = pool size - 1 (slot 0 is the root tableau) whenever no batch is between solve_local and apply.
+int bslv_benson_pool_stats(bslv_benson *h, long out[4])
+{
+    if (!h || !out) return BSLV_E_ARG;
+    std::lock_guard<std::mutex> lk(h->slot_mu);
+    long resident = 0;
+    for (auto &pr : h->parents) {
+        if (pr.first == -2) { resident++; continue; }
+        auto it = h->facet_slot.find(pr.first);
+        if (it != h->facet_slot.end() && it->second == pr.second) resident++;
+    }
+    long held = 0;
+    for (int c = 0; c < 2; c++) for (int s : h->ctx[c].l_slot) if (s >= 0) held++;
+    out[0] = (long)h->free_slots.size(); out[1] = resident; out[2] = held; out[3] = h->pool_slots;
     return 0;
 }
 // pre-images (option -s): x[n] of a vertex of the upper image / (u[m], w[q]) of a vertex of the lower image.  Returns 0 and

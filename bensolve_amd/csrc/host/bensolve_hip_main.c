@@ -104,7 +104,7 @@ int main(int argc, char **argv)
         if (!lf) { printf("unable to open file %s", lfile); return 1; }
         fprintf(lf, "BENSOLVE: VLP solver, bensolve_hip (MI355X engine behind the BENSOLVE 2.0.1 file formats)\n");
         fprintf(lf, "Problem parameters\n");
-        fprintf(lf, "  problem file:      %s\n", lfile);
+        fprintf(lf, "  problem file:      %s\n", file);      /* (the reference prints the log's own name here: a shadowed variable, bslv_main.c:348,367) */
         fprintf(lf, "  problem rows:      %7d\n", v->m);
         fprintf(lf, "  problem columns:   %7d\n", v->n);
         fprintf(lf, "  matrix non-zeros:  %7ld\n", v->nz);

@@ -99,16 +99,22 @@ int bslv_vlp_read(const char *path, bslv_vlp **out, int *err_line)
                 if (tok_int(tok[9], &v->n_gen) || v->n_gen < 0) { rc = fail(v, "number of cone generating vectors missing or invalid"); goto done; }
                 if (tok_int(tok[10], &nzgen) || nzgen < 0) { rc = fail(v, "number of cone generator non-zeros missing or invalid"); goto done; }
             }
-            if ((double)v->m * v->n > 268435456.0) { rc = fail(v, "problem too large for the dense path (sparse-A path is SURVEY 8f rank 4)"); goto done; }
-            size_t mn = (size_t)(v->m ? v->m : 1) * (v->n ? v->n : 1), qn = (size_t)v->q * (v->n ? v->n : 1);
+            /* the header of an untrusted file sizes every allocation: bound each count before anything is allocated (q <= 16 is
+             * what the polyhedron engine supports; 2^28 dense entries is the limit of the dense path), sizes in size_t */
+            if (v->q > 16) { rc = fail(v, "more than 16 objectives are not supported"); goto done; }
+            if (v->m > 100000000 || v->n > 100000000 || v->n_gen > 1000000) { rc = fail(v, "problem dimensions out of range"); goto done; }
+            if ((double)v->m * v->n > 268435456.0 || (double)v->q * v->n > 268435456.0) { rc = fail(v, "problem too large for the dense path (sparse-A path is SURVEY 8f rank 4)"); goto done; }
+            size_t mn = (size_t)(v->m ? v->m : 1) * (size_t)(v->n ? v->n : 1), qn = (size_t)v->q * (size_t)(v->n ? v->n : 1);
             v->A = (double *)calloc(mn, sizeof(double)); v->P = (double *)calloc(qn, sizeof(double));
-            v->rtype = (char *)malloc(v->m + 1); v->ctype = (char *)malloc(v->n + 1);
-            memset(v->rtype, 'x', v->m + 1); memset(v->ctype, 'x', v->n + 1);
-            v->rlb = (double *)calloc(v->m + 1, 8); v->rub = (double *)calloc(v->m + 1, 8);
-            v->clb = (double *)calloc(v->n + 1, 8); v->cub = (double *)calloc(v->n + 1, 8);
-            v->c = (double *)calloc(v->q, 8);
-            if (v->cone_gen != BSLV_CONE_DEFAULT) v->gen = (double *)calloc((size_t)v->q * (v->n_gen ? v->n_gen : 1), 8);
-            if (!v->A || !v->P || !v->rtype || !v->ctype) { rc = fail(v, "out of memory"); goto done; }
+            v->rtype = (char *)malloc((size_t)v->m + 1); v->ctype = (char *)malloc((size_t)v->n + 1);
+            v->rlb = (double *)calloc((size_t)v->m + 1, 8); v->rub = (double *)calloc((size_t)v->m + 1, 8);
+            v->clb = (double *)calloc((size_t)v->n + 1, 8); v->cub = (double *)calloc((size_t)v->n + 1, 8);
+            v->c = (double *)calloc((size_t)v->q, 8);
+            if (v->cone_gen != BSLV_CONE_DEFAULT) v->gen = (double *)calloc((size_t)v->q * (size_t)(v->n_gen ? v->n_gen : 1), 8);
+            if (!v->A || !v->P || !v->rtype || !v->ctype || !v->rlb || !v->rub || !v->clb || !v->cub || !v->c || (v->cone_gen != BSLV_CONE_DEFAULT && !v->gen)) {
+                rc = fail(v, "out of memory"); goto done;
+            }
+            memset(v->rtype, 'x', (size_t)v->m + 1); memset(v->ctype, 'x', (size_t)v->n + 1);
             have_p = 1;
             continue;
         }

@@ -841,11 +841,13 @@ static int ensure_batch(bslv_lpq *h, int B)
 {
     if (B <= h->Bcap) return 0;
     int cap = std::max(B, h->Bcap * 2);
-    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    // every pointer is cleared as it is freed: when one of the allocations below fails, destroy() and a later ensure_batch()
+    // see nullptr for what is gone instead of freeing it a second time
+    auto fr = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d); fr(h->work_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d);
-    if (h->status_h) (void)hipHostFree(h->status_h);
-    if (h->active_h) (void)hipHostFree(h->active_h);
+    if (h->status_h) { (void)hipHostFree(h->status_h); h->status_h = nullptr; }
+    if (h->active_h) { (void)hipHostFree(h->active_h); h->active_h = nullptr; }
     h->Bcap = 0;
     HIP_TRY(hipMalloc(&h->src_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->dst_d, cap * sizeof(int)));

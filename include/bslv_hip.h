@@ -205,8 +205,14 @@ int  bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, i
 int  bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *pivots_out, int *lockstep_out);
 int  bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *records, long *stats);
 int  bslv_benson_unprocessed_left(const bslv_benson *h);
-/* batch selection: 1 = newest vertices first (default), 2 = spread evenly over the unprocessed queue */
+/* batch selection: 1 = newest vertices first (default), 2 = spread evenly over the unprocessed queue, 3 = newest first but at
+ * most `cap` children of one cut per batch, chosen from a window of `window` batches (set_sibling_rule; default 1, 8): the
+ * children of one cut mostly see the same facet of the upper image, so their LPs return the same cut -- the reference's
+ * sequential loop never solves them, because the first copy of the cut removes the siblings (bslv_algs.c:1030-1080) */
 int  bslv_benson_set_policy(bslv_benson *h, int policy);
+int  bslv_benson_set_sibling_rule(bslv_benson *h, int cap, int window);
+/* tableau pool: out[0] free slots, [1] resident warm-start sources, [2] held by a batch in flight, [3] pool size */
+int  bslv_benson_pool_stats(bslv_benson *h, long out[4]);
 int  bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots);
 /* size of the P2 model after the driver's presolve (rows of A with a single non-zero become column bounds and leave the
  * LP; the hypercube rows of S-degenerate, ex/example10.m:21-24): M x N of init_P2 (bslv_algs.c:574-664) minus the folded rows */

@@ -18,6 +18,15 @@ int obenson_phase2_primal(int m, int n, int q, const double *A, const double *P,
                           const double *R, int r, const double *c, double eps, long max_lps,
                           opoly **poly_out, obenson_stats *st)
 {
+    return obenson_phase2_primal_ex(m, n, q, A, P, rtype, rlb, rub, ctype, clb, cub, R, r, c, eps, max_lps, 0, 0, poly_out, st);
+}
+
+int obenson_phase2_primal_ex(int m, int n, int q, const double *A, const double *P,
+                             const char *rtype, const double *rlb, const double *rub,
+                             const char *ctype, const double *clb, const double *cub,
+                             const double *R, int r, const double *c, double eps, long max_lps,
+                             int order, long warm_lps, opoly **poly_out, obenson_stats *st)
+{
     memset(st, 0, sizeof(*st));
     double t_start = now();
     /* base problem [A 0; -P I] (lp_init, bslv_main.c:258; bslv_vlp.c:376-453) + P2 extras */
@@ -78,9 +87,13 @@ int obenson_phase2_primal(int m, int n, int q, const double *A, const double *P,
     /* PART 2 */
     while (!rc) {
         int ideal, idx;
-        if (opoly_next(up, val, &ideal, &idx)) break;
+        if (order == 1 ? opoly_next_newest(up, val, &ideal, &idx) : opoly_next(up, val, &ideal, &idx)) break;
         if (ideal) { opoly_mark(up, idx); continue; }
         if (max_lps > 0 && st->lps >= max_lps) { rc = 3; break; }
+        if (warm_lps > 0 && st->lps >= warm_lps && st->warm_lps == 0) {      /* end of the untimed-by-the-caller warm-up */
+            st->warm_lps = st->lps; st->warm_cuts = st->cuts; st->warm_pivots = olp_pivots(lp);
+            st->warm_new_vertices = opoly_new_vertices(up); st->warm_secs = now() - t_start;
+        }
         for (int j = 0; j < r; j++) {
             double ub = 0;
             for (int k = 0; k < q; k++) ub += R[(size_t)k * r + j] * val[k];

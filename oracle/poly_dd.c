@@ -429,6 +429,18 @@ int opoly_next(opoly *p, double *val, int *ideal, int *idx)
     return 1;
 }
 
+/* measurement variant (not the reference's rule): the NEWEST live slot without the sltn mark */
+int opoly_next_newest(opoly *p, double *val, int *ideal, int *idx)
+{
+    for (int i = p->nv - 1; i >= 0; i--)
+        if (p->used[i] && !p->sltn[i]) {
+            memcpy(val, p->X + (size_t)i * p->d, p->d * sizeof(double));
+            *ideal = p->ideal[i]; *idx = i;
+            return 0;
+        }
+    return 1;
+}
+
 void opoly_mark(opoly *p, int idx) { p->sltn[idx] = 1; }
 
 /* a dual slot is live iff it was applied and some live primal element still lies on it

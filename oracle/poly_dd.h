@@ -39,6 +39,7 @@ int    opoly_init(opoly *p);
 /* poly__get_vrtx (bslv_poly.c:210-226): lowest live primal slot without the sltn mark;
  * returns 1 when none is left */
 int    opoly_next(opoly *p, double *val, int *ideal, int *idx);
+int    opoly_next_newest(opoly *p, double *val, int *ideal, int *idx);   /* measurement variant: the newest such slot */
 void   opoly_mark(opoly *p, int idx);                 /* ST_BT(primal.sltn, idx) */
 /* poly__update_adjacence on the dual side (bslv_poly.c:992-1010) */
 void   opoly_dual_adjacency(opoly *p);

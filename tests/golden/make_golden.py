@@ -102,6 +102,63 @@ def make_poly():
     np.savez_compressed(os.path.join(HERE, "poly_ref.npz"), **out)
 
 
+def read_objective_columns(path):
+    """columns of P (the o lines of a .vlp file, bslv_vlp.c:434-457) as rows"""
+    q = n = None
+    ent = []
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "p":
+            n, q = int(t[4]), int(t[6])
+        elif t[0] == "o":
+            ent.append((int(t[1]), int(t[2]), float(t[3])))
+    P = np.zeros((n, q))
+    for k, j, v in ent:
+        P[j - 1, k - 1] = v
+    return P
+
+
+def poly_cases_large():
+    """SURVEY.md 8c's list: the random-tangent synthetics at the sizes of BASELINE.md section 2, the dual cone of ex06 and the
+    lattice directions of ex10 (its 343 objective columns, integers in {-3..3}^3: many parallel and cohyperplanar cuts)."""
+    cases = {}
+    for q, N, seed in [(3, 2000, 31), (5, 200, 32), (5, 1000, 33), (8, 60, 34)]:
+        cases["tangent_q%d_N%d" % (q, N)] = (q, 0, None, False, ph.tangent_halfspaces(q, N, seed), None, q + 3)
+    gens = read_cone("/root/reference/ex/ex06.vlp")
+    cases["cone_ex06"] = (gens.shape[1], 0, None, True, gens, [1] * len(gens), None)
+    L = read_objective_columns("/root/reference/ex/ex10.vlp")
+    L = L[np.abs(L).sum(axis=1) > 0]
+    cases["lattice_ex10"] = (3, 0, None, False, L / 3.0, None, None)
+    return cases
+
+
+def digest_pairs(pairs):
+    """SHA-256 of a canonical index set (sorted pairs, int64 little endian)"""
+    import hashlib
+    a = np.array(sorted(pairs), np.int64).reshape(-1, 2)
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest(), len(a)
+
+
+def make_poly_large():
+    """coordinates in full, index sets as (SHA-256, count) of the canonical relabelling: see tests/test_oracle_poly.py"""
+    out, meta = {}, {}
+    for name, case in poly_cases_large().items():
+        rcs, can = run_case("ref", case)
+        q, v2h, c, apex, vals, ideals, init_after = case
+        out[name + "/in_vals"] = np.asarray(vals, float)
+        out[name + "/in_ideals"] = np.asarray([0] * len(vals) if ideals is None else ideals)
+        out[name + "/in_meta"] = np.array([q, v2h, int(apex), -1 if init_after is None else init_after])
+        out[name + "/rc"] = np.asarray(rcs)
+        for k in ("X", "pi", "Y", "di"):
+            out[name + "/" + k] = can[k]
+        meta[name] = {k: digest_pairs(can[k]) for k in ("E", "I", "DE")}
+        print("poly large", name, "primal", len(can["X"]), "dual", len(can["Y"]), meta[name])
+    np.savez_compressed(os.path.join(HERE, "poly_ref_large.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "poly_ref_large.json"), "w"), indent=1)
+
+
 def make_lp():
     from scipy.optimize import linprog
     rec = []
@@ -165,6 +222,10 @@ def make_hybrid():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "large":
+        make_poly_large()
+        sys.exit(0)
     make_poly()
+    make_poly_large()
     make_lp()
     make_hybrid()

@@ -108,11 +108,15 @@ class OracleLP:
 class BensonStats(ctypes.Structure):
     _fields_ = [("lps", ctypes.c_long), ("cuts", ctypes.c_long), ("pivots", ctypes.c_long),
                 ("new_vertices", ctypes.c_long), ("secs_total", ctypes.c_double), ("secs_lp", ctypes.c_double),
-                ("secs_poly", ctypes.c_double), ("status", ctypes.c_int)]
+                ("secs_poly", ctypes.c_double), ("status", ctypes.c_int),
+                ("warm_lps", ctypes.c_long), ("warm_cuts", ctypes.c_long), ("warm_pivots", ctypes.c_long),
+                ("warm_new_vertices", ctypes.c_long), ("warm_secs", ctypes.c_double)]
 
 
-def benson_phase2_primal(prob, R=None, c=None, eps=1e-7, max_lps=0):
-    """Sequential CPU Benson phase 2 (oracle/benson_cpu.c).  Returns (FlatPoly-like dump dict, stats)."""
+def benson_phase2_primal(prob, R=None, c=None, eps=1e-7, max_lps=0, order=0, warm_lps=0):
+    """Sequential CPU Benson phase 2 (oracle/benson_cpu.c).  Returns (rc, FlatPoly-like dump, stats).
+    order 0 = the reference's vertex order (lowest slot), 1 = newest first; warm_lps: snapshot of the counters after that
+    many LPs in stats.warm_* (bench.py rates the LPs behind the warm-up)."""
     import poly_harness as ph
     L = load()
     m, n, q = prob["m"], prob["n"], prob["q"]
@@ -126,11 +130,12 @@ def benson_phase2_primal(prob, R=None, c=None, eps=1e-7, max_lps=0):
     rlb, rub, clb, cub = f8(prob["rlb"]), f8(prob["rub"]), f8(prob["clb"]), f8(prob["cub"])
     out = ctypes.c_void_p()
     st = BensonStats()
-    L.obenson_phase2_primal.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 8 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                                                                  ctypes.c_double, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
-    rc = L.obenson_phase2_primal(m, n, q, A.ctypes.data, P.ctypes.data, rt.ctypes.data, rlb.ctypes.data, rub.ctypes.data,
-                                 ct.ctypes.data, clb.ctypes.data, cub.ctypes.data, R.ctypes.data, r, c.ctypes.data,
-                                 eps, max_lps, ctypes.byref(out), ctypes.byref(st))
+    L.obenson_phase2_primal_ex.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 8 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                                                     ctypes.c_double, ctypes.c_long, ctypes.c_int, ctypes.c_long,
+                                                                                     ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.obenson_phase2_primal_ex(m, n, q, A.ctypes.data, P.ctypes.data, rt.ctypes.data, rlb.ctypes.data, rub.ctypes.data,
+                                    ct.ctypes.data, clb.ctypes.data, cub.ctypes.data, R.ctypes.data, r, c.ctypes.data,
+                                    eps, max_lps, order, warm_lps, ctypes.byref(out), ctypes.byref(st))
     fp = ph.FlatPoly.__new__(ph.FlatPoly)
     fp.L, fp.pre, fp.d, fp.h = L, "opoly_", q, out
     if not getattr(L, "_poly_bound", False):

@@ -75,7 +75,12 @@ def test_s_small_complete_run_matches_oracle():
     got = ph.canonical(eng.poly_dump(), decimals=6)
     paths = eng.poly_call("path_stats")
     eng.close()
-    ph.assert_benson_results_agree(got, exp)
+    # ALLOW-LIST: 8237 vertices / 8186 facets on both sides; measured 10 points (both directions summed) without a partner
+    # within 1e-6 and one edge more on one side.  Both runs stop at eps = 1e-9 = the polyhedron code's own on-plane band
+    # (bslv_poly.h:47; a smaller eps makes the REFERENCE loop forever: poly__add_vrtx's EXIT_FAILURE is ignored at
+    # bslv_algs.c:1072 and the vertex is never marked), so where an LP has several optimal duals the two cut orders keep
+    # different supporting hyperplanes through the same low-dimensional face: slivers of that width
+    mode = ph.assert_benson_results_agree(got, exp, allow_sliver=("S-small to termination: different cut order at eps = POLY_EPS", 24))
     assert len(exp["X"]) > 5000 and paths["single_cuts"] > 100
 
 
@@ -84,6 +89,10 @@ import json
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = np.load(os.path.join(HERE, "golden", "hybrid.npz"))
+
+
+# hybrid goldens on which the reference's eps = 1e-7 run and the batched run are known to differ by eps-slivers
+SLIVER_ALLOWED = {"syn_40x20_q4_s9"}
 
 
 def _sort_rows(t, X, decimals=6):
@@ -111,7 +120,15 @@ def test_phase2_matches_hybrid_golden(name, args):
         assert np.array_equal(1 - can["pi"], t)
         np.testing.assert_allclose(can["X"], X, rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(can["Y"], Y, rtol=1e-6, atol=1e-6)
-    else:   # eps-level sliver facets (see tests/test_oracle_benson.py)
+        ph._record_mode("exact")
+    else:
+        # ALLOW-LIST (the only place besides test_cli_gpu's hybrid comparisons): the golden is a run of the reference driver
+        # at its default eps = 1e-7 (the committed fixture cannot be re-run at another eps on the GPU box), with the
+        # reference's sequential cut order; a vertex whose LP value lies in (1e-9, 1e-7] is accepted there and cut here
+        # or vice versa: sliver facets 1e-7 wide
+        assert name in SLIVER_ALLOWED, "%s: counts differ from the reference golden (%d/%d vs %d/%d) and the case is not allow-listed" % (
+            name, len(can["X"]), len(can["Y"]), len(X), len(Y))
+        ph._record_mode("sliver")
         from scipy.spatial import cKDTree
         for A, B in ((can["X"], X), (X, can["X"])):
             dist, _ = cKDTree(B).query(A)
@@ -161,7 +178,7 @@ def _rank_worker(rank, world, port, args, batch, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     prob = synth.covering_vlp(*args)
-    eng = BensonEngine(prob, eps=1e-7, pool_slots=512)
+    eng = BensonEngine(prob, eps=1e-9, pool_slots=512)
     assert eng.start() == 0
     steps = 0
     while True:
@@ -190,7 +207,7 @@ def test_two_ranks_match_single():
     for k in ("pu", "pi", "E", "I", "X", "Y", "du"):
         assert np.array_equal(d0[k], d1[k]), "replicas diverged in " + k
     prob = synth.covering_vlp(*args)
-    eng = BensonEngine(prob, eps=1e-7, pool_slots=512)
+    eng = BensonEngine(prob, eps=1e-9, pool_slots=512)
     assert eng.start() == 0
     eng.run(batch)
     eng.poly_call("dual_adjacency")
@@ -204,11 +221,11 @@ def test_pipelined_lp_poly_overlap_matches_oracle(m, n, q, seed, batch):
     """LPs of batch k on a second host thread while the cuts of batch k-1 are applied"""
     from bensolve_amd.benson import PipelinedStepper
     prob = synth.covering_vlp(m, n, q, seed)
-    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=1e-7)
+    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=1e-9)
     fp.dual_adjacency()
     exp = ph.canonical(fp.dump(), decimals=6)
     fp.close()
-    eng = BensonEngine(prob, eps=1e-7, pool_slots=max(8 * batch, 128))
+    eng = BensonEngine(prob, eps=1e-9, pool_slots=max(8 * batch, 128))
     assert eng.start() == 0
     PipelinedStepper(eng, batch).run()
     eng.poly_call("dual_adjacency")
@@ -251,3 +268,57 @@ print(json.dumps(dict(X=c["X"].tolist(), pi=c["pi"].tolist(), pivots=eng.totals(
     # the retry of undefined LPs (from the root tableau), forced on every other LP of every batch
     np.testing.assert_allclose(np.array(out["retry"]["X"]), np.array(out["64"]["X"]), rtol=1e-7, atol=1e-7)
     assert out["retry"]["pi"] == out["64"]["pi"] and out["retry"]["pivots"] > out["64"]["pivots"]
+
+
+@pytest.mark.parametrize("policy", [1, 2, 3])
+def test_tableau_pool_accounting_with_a_tiny_pool(policy):
+    """Slots evicted while they still serve as warm-start sources of the batch are re-queued and must come back to the
+    free list later (they used to leak: the pool shrank until 'tableau pool exhausted' on a solvable problem).  Tiny pool,
+    every batch policy, run to termination: free + resident = pool - 1 (slot 0 is the root tableau) after every step, and
+    the result equals the oracle's."""
+    prob = synth.covering_vlp(60, 30, 3, 7)
+    batch, pool = 16, 40
+    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=1e-9)
+    fp.dual_adjacency()
+    exp = ph.canonical(fp.dump(), decimals=6)
+    fp.close()
+    eng = BensonEngine(prob, eps=1e-9, pool_slots=pool)
+    eng.set_policy(policy)
+    assert eng.start() == 0
+    steps = 0
+    while True:
+        s = eng.step(batch)
+        steps += 1
+        ps = eng.pool_stats()
+        assert ps["held"] == 0 and ps["free"] + ps["resident"] == pool - 1, (steps, ps)
+        if (s["lps"] == 0 and s["left"] == 0) or steps > 5000:
+            break
+    eng.poly_call("dual_adjacency")
+    got = ph.canonical(eng.poly_dump(), decimals=6)
+    eng.close()
+    assert steps < 5000
+    ph.assert_benson_results_agree(got, exp)
+
+
+def test_one_child_per_cut_policy_solves_fewer_redundant_lps():
+    """batch policy 3 (at most one child of a cut per batch): the siblings' LPs, which return the cut their sibling already
+    delivered, are not solved -- the first copy of the cut removes or confirms them -- and the image is the same"""
+    prob = synth.covering_vlp(120, 60, 4, 11)
+    res = {}
+    for policy in (1, 3):
+        eng = BensonEngine(prob, eps=1e-9, pool_slots=2048)
+        eng.set_policy(policy)
+        assert eng.start() == 0
+        lps = red = 0
+        for _ in range(100000):
+            s = eng.step(128)
+            lps += s["lps"]; red += s["redundant"]
+            if s["lps"] == 0 and s["left"] == 0:
+                break
+        eng.poly_call("dual_adjacency")
+        res[policy] = (ph.canonical(eng.poly_dump(), decimals=6), lps, red)
+        eng.close()
+    # ALLOW-LIST: two runs of the HIP path itself with different batch compositions (53 655 vs 53 664 vertices, 54 791 facets
+    # on both sides, measured 122 points without a partner within 1e-6): eps-slivers as in test_s_small_complete_run_matches_oracle
+    ph.assert_benson_results_agree(res[3][0], res[1][0], allow_sliver=("two batch policies on a q=4 problem with 5e4 vertices: different cut order at eps = POLY_EPS", 300))
+    assert res[3][2] * 2 < res[1][2], "policy 3 should at least halve the redundant LPs: %d vs %d" % (res[3][2], res[1][2])

@@ -120,6 +120,7 @@ def test_cli_ex01_known_answer(tmp_path):
     assert got == sorted([(1, 0.0, 4.0), (1, -6.0, 6.0), (0, 1.0, 0.0), (0, -1.0, 1.0)])
     # <name>.log carries the fields of the reference's log (bslv_main.c:346-397)
     log = open(base + ".log").read()
+    assert "problem file:      %s" % os.path.join(EXDIR, "ex01.vlp") in log          # the input file (the reference prints the log's own name: a quirk)
     for frag in ("Problem parameters", "problem rows:            2", "problem columns:         2", "bounded:            no (run phases 0 to 2)",
                  "alg_phase2:         primal", "# primal solution points:           2", "# primal solution directions:       2", "# LPs:"):
         assert frag in log, (frag, log)

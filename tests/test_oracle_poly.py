@@ -42,6 +42,28 @@ def test_oracle_matches_reference_golden(name):
     ph.assert_same(can, golden_canonical(name))
 
 
+import json
+GOLD_L = np.load(os.path.join(HERE, "golden", "poly_ref_large.npz"))
+META_L = json.load(open(os.path.join(HERE, "golden", "poly_ref_large.json")))
+
+
+@pytest.mark.parametrize("name", sorted(META_L))
+def test_oracle_matches_reference_golden_at_survey_sizes(name):
+    """SURVEY.md 8c's sizes (q=3 N=2000, q=5 N=200 / N=1000, q=8 N=60, ex06's dual cone, ex10's lattice directions): the
+    reference's own bslv_poly.c produced the fixture (tests/golden/make_golden.py large); coordinates at 1e-9, index sets
+    bit-exact by SHA-256 of the canonical labelling"""
+    q, v2h, apex, init_after = [int(x) for x in GOLD_L[name + "/in_meta"]]
+    P = ph.FlatPoly("oracle", q, v2h)
+    if apex:
+        P.dual0_apex()
+    rcs = ph.run_sequence(P, GOLD_L[name + "/in_vals"], list(GOLD_L[name + "/in_ideals"]), None if init_after < 0 else init_after)
+    P.dual_adjacency()
+    can = ph.canonical(P.dump())
+    P.close()
+    assert list(rcs) == list(GOLD_L[name + "/rc"])
+    ph.assert_matches_large_golden(can, GOLD_L, META_L, name)
+
+
 @pytest.mark.skipif(not ph.ref_available(), reason="oracle/_ref/libref_poly.so only exists in the build container")
 @pytest.mark.parametrize("q,N,seed", [(3, 500, 21), (4, 150, 22), (5, 150, 23)])
 def test_oracle_matches_compiled_reference_live(q, N, seed):

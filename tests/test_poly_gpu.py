@@ -176,6 +176,39 @@ def test_gpu_matches_reference_golden(name):
     ph.assert_same(can, exp)
 
 
+import json as _json
+_GOLD_L = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "poly_ref_large.npz"))
+_META_L = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "poly_ref_large.json")))
+
+
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("name", sorted(_META_L))
+def test_gpu_matches_reference_golden_at_survey_sizes(name, batched):
+    """the HIP engine against the reference's own results at SURVEY.md 8c's sizes (27 418 vertices at q=5 N=1000, 28 681 at
+    q=8 N=60, ...): coordinates at 1e-9, adjacency / incidence / dual adjacency bit-exact (SHA-256 of the canonical sets).
+    batched: the cuts after the initial simplex go through bslv_poly_add_cuts (multi-cut rounds / hot chunks) instead of one
+    bslv_poly_add each."""
+    q, v2h, apex, init_after = [int(x) for x in _GOLD_L[name + "/in_meta"]]
+    vals, ideals = _GOLD_L[name + "/in_vals"], list(_GOLD_L[name + "/in_ideals"])
+    G = PolyEngine(q, v2h)
+    if apex:
+        G.dual0_apex()
+    if not batched:
+        rcs = ph.run_sequence(G, vals, ideals, None if init_after < 0 else init_after)
+        assert list(rcs) == list(_GOLD_L[name + "/rc"])
+    else:
+        k0 = len(vals) if init_after < 0 else init_after
+        for k in range(k0):
+            G.add(vals[k], ideals[k])
+        assert G.init() == 0
+        if k0 < len(vals):
+            G.add_cuts(vals[k0:], ideals[k0:])
+    G.dual_adjacency()
+    can = ph.canonical(G.dump())
+    G.close()
+    ph.assert_matches_large_golden(can, _GOLD_L, _META_L, name)
+
+
 def test_full_size_properties_q5_N1000():
     """BASELINE-size poly-only synthetic (q=5, N=1000; the reference: 27 496 live vertices):
     size-independent properties instead of an oracle run."""

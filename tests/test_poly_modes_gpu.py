@@ -188,33 +188,93 @@ def test_smid_benson_steps_identical_in_all_modes():
             assert np.array_equal(dumps[name][key], dumps["default"][key]), (name, key)
 
 
+def _host_edge_test_sample(d, npairs, seed):
+    """Independent recomputation of the adjacency prune on the host for sampled pairs of the LARGEST facet of a dump: two
+    vertices are adjacent iff they share at least dim-1 facets and no third live vertex lies on all of them (edge_test,
+    bslv_poly.c:467-512).  Returns (pairs checked, mismatches, adjacent pairs among them)."""
+    dim = d["d"]
+    live = d["pu"].astype(bool)
+    I = d["I"][live[d["I"][:, 0]]]
+    order = np.argsort(I[:, 1], kind="stable")
+    fac, verts = I[order, 1], I[order, 0]
+    fstart = np.searchsorted(fac, np.arange(fac.max() + 2))
+    members = lambda f: verts[fstart[f]:fstart[f + 1]]            # ascending vertex ids (I is vertex-major, stable sort)
+    order2 = np.argsort(I[:, 0], kind="stable")
+    vv, ff = I[order2, 0], I[order2, 1]
+    vstart = np.searchsorted(vv, np.arange(len(d["pu"]) + 1))
+    inc = lambda v: ff[vstart[v]:vstart[v + 1]]
+    sizes = np.diff(fstart)
+    big = int(np.argmax(sizes))
+    mem = members(big)
+    E = d["E"]
+    ekeys = set((np.minimum(E[:, 0], E[:, 1]).astype(np.int64) << 32 | np.maximum(E[:, 0], E[:, 1]).astype(np.int64)).tolist())
+    rng = np.random.default_rng(seed)
+    # half of the sample: random pairs of the facet (mostly non-adjacent); the other half: edges the engine reports inside it
+    inbig = np.zeros(len(d["pu"]), bool); inbig[mem] = True
+    Ein = E[inbig[E[:, 0]] & inbig[E[:, 1]]]
+    pairs = [tuple(sorted(map(int, rng.choice(mem, 2, replace=False)))) for _ in range(npairs // 2)]
+    pairs += [tuple(sorted(map(int, Ein[k]))) for k in rng.choice(len(Ein), min(npairs // 2, len(Ein)), replace=False)]
+    bad = nadj = 0
+    for u, v in pairs:
+        M = np.intersect1d(inc(u), inc(v), assume_unique=True)
+        adj = False
+        if dim == 1 or len(M) >= dim - 1:
+            Ms = sorted(M.tolist(), key=lambda f: sizes[f])
+            cand = members(Ms[0])
+            for f in Ms[1:]:
+                if len(cand) <= 2:
+                    break
+                cand = np.intersect1d(cand, members(f), assume_unique=True)
+            adj = len(cand) == 2                                  # u and v themselves
+        nadj += adj
+        bad += adj != (((u << 32) | v) in ekeys)
+    return len(pairs), bad, nadj, int(sizes[big])
+
+
 def test_large_facets_member_list_prune_equals_full_scan():
     """S-degenerate at full size, first five steps: new facets of 10^4-10^5 elements go through the multi-kernel prune with the
-    row-tiled pair kernel, which confirms edges against the members of the smallest mutual facet.  The same steps with the
-    edges confirmed against ALL elements of the facet: the same polyhedron bit for bit.  (The fifth step brings a facet of
-    114 296 elements: 2.5e7 pair blocks, more than a one-dimensional grid of 256-thread workgroups can hold -- the runtime
-    wraps such a grid silently, which is why the large-facet kernel uses a two-dimensional one.)"""
+    row-tiled pair kernel, which confirms edges against the members of the smallest mutual facet.  Three arms: (1) that
+    default, (2) edges confirmed against ALL elements of the facet, (3) the one-dimensional, untiled pair kernel
+    (k_pair_flags_bits; only the first four steps: the fifth brings a facet of 114 296 elements = 2.5e7 pair blocks, more than
+    a one-dimensional grid of 256-thread workgroups can hold -- the runtime wraps such a grid silently, which is why the
+    large-facet kernel uses a two-dimensional one and the one-dimensional launch refuses).  Same polyhedron bit for bit in all
+    arms; and, independent of all three kernels, the adjacency of sampled pairs of the largest facet is recomputed on the
+    host from the incidence lists."""
     import hashlib
     from bensolve_amd import synth
     from bensolve_amd.benson import BensonEngine
     prob = synth.CONFIGS["S-degenerate"]()
     out = {}
-    for name, lists in (("member lists", 1), ("full scan", 0)):
+
+    def digest(d):
+        h = hashlib.sha256()
+        for key in ("pu", "pi", "du", "di", "X", "Y", "E", "I"):
+            h.update(np.ascontiguousarray(d[key]).tobytes())
+        return h.hexdigest(), int(d["pu"].sum()), len(d["E"])
+
+    for name, lists, steps in (("member lists", 1, 5), ("full scan", 0, 5), ("untiled", 1, 4)):
         eng = BensonEngine(prob, eps=1e-7, pool_slots=4 * 64 + 64)
         eng.poly_call("debug_set", 5, lists)
+        if name == "untiled":
+            eng.poly_call("debug_set", 4, 1 << 30)            # no facet is 'large': one-dimensional k_pair_flags_bits for every fallback prune
         assert eng.start() == 0
-        for _ in range(5):
+        d4 = None
+        for it in range(steps):
             nl, nt = eng.collect(64, 0, 1)
             rec, piv, ls = eng.solve_local(nl)
             assert np.all(rec[:, 1] == 4)
             eng.apply(rec)
+            if it == 3:
+                d4 = digest(eng.poly_dump())
         d = eng.poly_dump()
         paths = eng.poly_call("path_stats")
         eng.close()
-        h = hashlib.sha256()
-        for key in ("pu", "pi", "du", "di", "X", "Y", "E", "I"):
-            h.update(np.ascontiguousarray(d[key]).tobytes())
-        out[name] = (h.hexdigest(), int(d["pu"].sum()), len(d["E"]), paths)
-    assert out["member lists"][3]["member_list_prunes"] > 20 and out["full scan"][3]["member_list_prunes"] == 0, out
-    assert out["member lists"][1] > 900000
-    assert out["member lists"][:3] == out["full scan"][:3], out
+        out[name] = (digest(d), d4, paths)
+        if name == "member lists":
+            n, bad, nadj, fsize = _host_edge_test_sample(d, 1200, 7)
+            assert fsize > 50000 and n >= 1000 and nadj >= 300, (n, nadj, fsize)
+            assert bad == 0, "%d of %d sampled pairs of the largest facet (%d elements) disagree with the host edge test" % (bad, n, fsize)
+    assert out["member lists"][2]["member_list_prunes"] > 20 and out["full scan"][2]["member_list_prunes"] == 0 and out["untiled"][2]["member_list_prunes"] == 0, out
+    assert out["member lists"][0][1] > 900000
+    assert out["member lists"][0] == out["full scan"][0], out
+    assert out["member lists"][1] == out["full scan"][1] == out["untiled"][1], out       # after four steps, all three kernels

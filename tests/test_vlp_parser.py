@@ -116,6 +116,11 @@ def test_generated_file_roundtrips_bit_exact(tmp_path):
     ("p vlp min 1 1 1 1 1\nz 1\ne\n", "line designator"),
     ("p vlp min 1 1 1 1 1\na 1 1 abc\ne\n", "coefficient missing or invalid"),
     ("a 1 1 1\n", "problem line"),
+    # headers of untrusted files must not size an allocation before they are bounded
+    ("p vlp min 0 2147483647 0 1 0\ne\n", "out of range"),
+    ("p vlp min 1 1 1 2000000000 1\ne\n", "more than 16 objectives"),
+    ("p vlp min 100000 100000 1 2 1\ne\n", "too large for the dense path"),
+    ("p vlp min 1 1 1 2 1 cone 2000000000 1\ne\n", "out of range"),
     ("p vlp min 1 1 1 1 1\na 1 1 1\n", "end of file"),
 ])
 def test_malformed_files_are_rejected(tmp_path, text, frag):
