@@ -225,12 +225,11 @@ __device__ __forceinline__ unsigned long long spread32(unsigned x)
     return v;
 }
 template <int D, bool TOUCH>
-__global__ __launch_bounds__(PB) void k_classify_batch_t(PolyView P, const double *__restrict__ hps, int B, int nv,
-                                                         unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
-                                                         int *__restrict__ tc, int *__restrict__ t1)
+__device__ __forceinline__ void classify_batch_body(const PolyView &P, const double *__restrict__ hps, int B, int nv,
+                                                    unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
+                                                    int *__restrict__ tc, int *__restrict__ t1, const int i)
 {
     const int d = D > 0 ? D : P.d;
-    const int i = blockIdx.x * PB + threadIdx.x;
     bool live = false, ideal = false;
     double x[D > 0 ? D : MAXD];
 #pragma unroll
@@ -299,6 +298,13 @@ __global__ __launch_bounds__(PB) void k_classify_batch_t(PolyView P, const doubl
         }
     }
     if (TOUCH && i < nv) { tc[i] = touch; t1[i] = first; }
+}
+template <int D, bool TOUCH>
+__global__ __launch_bounds__(PB) void k_classify_batch_t(PolyView P, const double *__restrict__ hps, int B, int nv,
+                                                         unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
+                                                         int *__restrict__ tc, int *__restrict__ t1)
+{
+    classify_batch_body<D, TOUCH>(P, hps, B, nv, out, anyminus, tc, t1, (int)(blockIdx.x * PB + threadIdx.x));
 }
 
 static void launch_classify_batch(hipStream_t s, PolyView P, const double *hps, int B, int nv, unsigned long long *out, unsigned *anyminus,
@@ -1698,12 +1704,30 @@ __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const uns
     }
     if (lane < qn) sweep(q[lane]);
 }
-__global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
-                                                int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg,
-                                                const CutDev *cd, int *abort_flag, int *EP, Hp hn, int *counters_n, int *zlist_n)
+// V2 (rounds of independent cuts, poly_rounds2_kernels.inc): one workgroup per SELECTED cut s = blockIdx.x.  Its members are
+// the on-plane elements and new vertices of the round that belong to cut s; the result -- the adjacency bitmap over the pairs
+// of members, the members, their number, the number of adjacent pairs (-1: needs the multi-kernel prune) -- goes to global
+// memory and k_r2_k2emit writes the edges of all cuts in order.  The global facet counters (fcount / flocal) would be shared
+// by concurrent workgroups, so a prune that cannot use its LDS hash table asks for the fallback instead.
+struct RState;
+struct K2V2 {
+    const RState *st; const int *cutof; int *mem_g; unsigned *adj_g; int *cnt_g; int *nm_g; int adjw_cap; long long *pair_tests;
+};
+__device__ __forceinline__ void k2v2_sizes(const RState *st, int &S, int &go, int &nzero, int &nv0, int &ncross);
+__device__ void k2v2_check_members(const K2V2 &V, int vs, const int *s_mem, int nm, const int *members, int nzero);
+template <bool V2>
+__global__ __launch_bounds__(K2T) void k2_fused_t(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
+                                                  int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg,
+                                                  const CutDev *cd, int *abort_flag, int *EP, Hp hn, int *counters_n, int *zlist_n, K2V2 V)
 {
     extern __shared__ unsigned long long k2_dyn[];
-    if (blockIdx.x > 0) {
+    if (V2) {
+        int S, go;
+        k2v2_sizes(V.st, S, go, nzero, nv0, ncross);
+        if (!go || (int)blockIdx.x >= S) return;
+        cd = nullptr; dbg = nullptr; ne_dev = nullptr;
+    }
+    if (!V2 && blockIdx.x > 0) {
         // workgroups 1.. ride along: they classify the elements against the NEXT halfspace (the prune reads no
         // classes), which saves that launch
         classify_body(P, hn, cd->nv_new, counters_n, zlist_n, (blockIdx.x - 1) * K2T + threadIdx.x);
@@ -1733,20 +1757,50 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     __shared__ unsigned char s_islong[K2_MAXNM];
     __shared__ int s_nlong, s_nloc, s_carry;
     __shared__ int s_queue[K2T / WAVE][128];      // candidate pairs per wave (k2_pairs)
-    const int tid = threadIdx.x, nm = nzero + ncross, d = P.d;
+    const int tid = threadIdx.x, d = P.d;
+    int nm = nzero + ncross;
+    const int vs = (int)blockIdx.x;                 // V2: the selected cut of this workgroup
+    // V2: fallback request / empty result of cut vs (uniform callers)
+    auto v2_result = [&](int cnt, int n) { if (tid == 0) { V.cnt_g[vs] = cnt; V.nm_g[vs] = n; } };
+    if (V2) {
+        // P0a: the members of cut vs among the on-plane elements (members[0..nzero), slot order) and the new vertices
+        __shared__ int s_base;
+        if (tid == 0) s_base = 0;
+        __syncthreads();
+        const int ncand = nzero + ncross;
+        for (int c0 = 0; c0 < ncand; c0 += K2T) {
+            const int c = c0 + tid;
+            int v = -1;
+            if (c < ncand) { v = c < nzero ? members[c] : nv0 + (c - nzero); if (V.cutof[v] != vs) v = -1; }
+            Tri t{v >= 0, 0, 0};
+            Tri tot;
+            const Tri ex = block_exscan(t, &tot, lds);
+            if (v >= 0 && s_base + ex.a < K2_MAXNM) s_mem[s_base + ex.a] = v;
+            __syncthreads();
+            if (tid == 0) s_base += tot.a;
+            __syncthreads();
+        }
+        nm = s_base;
+        if (nm > K2_MAXNM) { v2_result(-1, nm); return; }          // too large for one workgroup: multi-kernel prune
+        k2v2_check_members(V, vs, s_mem, nm, members, nzero);
+        if (tid == 0 && nm >= 2) atomicAdd((unsigned long long *)V.pair_tests, (unsigned long long)((long long)nm * (nm - 1) / 2));
+        if (nm < 2) { v2_result(0, nm); return; }
+    }
     const long long npairs = (long long)nm * (nm - 1) / 2;
     const int nadjw = (int)((npairs + 31) / 32);
     unsigned *adj_bits = (unsigned *)k2_dyn;
     unsigned long long *bits = k2_dyn + (nadjw + 1) / 2;       // (behind the hash table when that is used, see P1)
     const long long bits_cap = (long long)lds_words - (nadjw + 1) / 2;
     if (bits_cap < 0) {                 // not even the pair bitmap fits (uniform): multi-kernel prune
+        if (V2) { v2_result(-1, nm); return; }
         if (threadIdx.x == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; mail->seq = seq; }
         return;
     }
     // P0: members (ZERO elements from k_emit2, then the new vertices), their lists
     for (int m = tid; m < nm; m += K2T) {
         int v;
-        if (m < nzero) v = members[m]; else { v = nv0 + (m - nzero); members[m] = v; }
+        if (V2) v = s_mem[m];
+        else if (m < nzero) v = members[m]; else { v = nv0 + (m - nzero); members[m] = v; }
         s_mem[m] = v; s_off[m] = P.inc_off[v]; s_len[m] = P.inc_len[v]; s_islong[m] = 0;
     }
     for (int w = tid; w < nadjw; w += K2T) adj_bits[w] = 0u;
@@ -1773,6 +1827,7 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     }
     __syncthreads();
     const bool use_hash = 2 * s_total <= K2_HASH && (long long)K2_HASH <= bits_cap;        // load factor <= 1/2 (uniform)
+    if (V2 && !use_hash) { v2_result(-1, nm); return; }
     int *hkey = (int *)bits, *hval = hkey + K2_HASH;                 // the table sits in front of the bit matrix
     if (use_hash) bits += K2_HASH;                                   // (K2_HASH ints of keys + K2_HASH of values = K2_HASH 64-bit words)
     const long long bcap = use_hash ? bits_cap - K2_HASH : bits_cap;
@@ -1802,6 +1857,7 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     K2_PHASE(2);
     const int W = (s_nloc + 63) >> 6, NW = (nm + 63) >> 6;
     unsigned long long *rows = bits + W * nm;        // rows[f * NW + k]: members on local facet f
+    if (V2 && (long long)W * nm + (long long)W * 64 * NW > bcap) { v2_result(-1, nm); return; }
     if ((long long)W * nm + (long long)W * 64 * NW > bcap) {             // uniform: every thread sees the same s_nloc
         if (!use_hash) k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
         if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; mail->seq = seq; }
@@ -1837,6 +1893,17 @@ __global__ __launch_bounds__(K2T) void k2_fused(PolyView P, int *members, int nz
     __syncthreads();
     K2_PHASE(4);
     K2_PHASE(5);
+    if (V2) {
+        // the bitmap, the members and the number of adjacent pairs go to global memory; k_r2_k2emit writes the edges
+        unsigned *ag = V.adj_g + (size_t)vs * V.adjw_cap;
+        int *mg = V.mem_g + (size_t)vs * K2_MAXNM;
+        int part = 0;
+        for (int w = tid; w < nadjw; w += K2T) { const unsigned x = adj_bits[w]; ag[w] = x; part += __popc(x); }
+        for (int m = tid; m < nm; m += K2T) mg[m] = s_mem[m];
+        const Tri tt = block_sum(Tri{part, 0, 0}, lds);
+        v2_result(tt.a, nm);
+        return;
+    }
     // P6: adjacent pairs in lexicographic order; the 32 pairs of a bitmap word are consecutive, so (i, j) is
     // decoded once per word and stepped
     int last_tot = 0;
@@ -2114,14 +2181,39 @@ __global__ void k_bench_fill(PolyView P, int nv, unsigned long long seed)
     P.inc_off[i] = 0;
 }
 #include "poly_rounds_kernels.inc"
+#include "poly_rounds2_kernels.inc"
+// debugging aid: a member list never holds an element twice
+__device__ void k2v2_check_members(const K2V2 &V, int vs, const int *s_mem, int nm, const int *members, int nzero)
+{
+    RState *st = const_cast<RState *>(V.st);
+    for (int m = threadIdx.x; m < nm; m += blockDim.x)
+        for (int m2 = m + 1; m2 < nm; m2++)
+            if (s_mem[m] == s_mem[m2] && atomicCAS(&st->err, 0, 4) == 0) {
+                int c1 = -1, c2 = -1;
+                for (int c = 0; c < nzero; c++) if (members[c] == s_mem[m]) { if (c1 < 0) c1 = c; else c2 = c; }
+                st->err_info[0] = vs; st->err_info[1] = m; st->err_info[2] = m2; st->err_info[3] = s_mem[m]; st->err_info[4] = c1; st->err_info[5] = c2; st->err_info[6] = nzero;
+            }
+}
+__device__ __forceinline__ void k2v2_sizes(const RState *st, int &S, int &go, int &nzero, int &nv0, int &ncross)
+{
+    S = st->S; go = st->go; nzero = st->nzero; nv0 = st->nv; ncross = st->ncross;
+}
+
 
 }  // namespace bslv
 
 using namespace bslv;
 
 struct RoundsBuf;
+struct Rounds2Buf;
 struct bslv_poly {
     RoundsBuf *rounds = nullptr;      // scratch of the multi-cut path
+    Rounds2Buf *rounds2 = nullptr;    // scratch of the device-selected rounds inside a hot chunk (poly_rounds2_host.inc)
+    bool rounds2_enabled = true;      // BSLV_NO_ROUNDS2=1 / bslv_poly_debug_set(h, 6, 0): hot chunks go through the single-cut pipeline
+    int chunk_cuts = 512;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
+    int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
+    int r2_min_cuts = 0;              // rounds go on while they hold at least this many cuts on average (debug_set key 8; 0: until the rounds hold one cut each; -1: always)
+    long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0;
     int batch_mode = 1;               // 0: one cut at a time, 1: rounds of independent cuts
     long rounds_run = 0, conf_pairs = 0, conf_cuts = 0;
     int dense_streak = 0, dense_skip = 0;   // adaptive skipping of the conflict pass (apply_cuts_rounds)
@@ -2592,9 +2684,9 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
             }
             seqB = ++h->mailseq;
             slotB = 2 + (h->k2flip ^= 1);
-            hipLaunchKernelGGL(k2_fused, dim3(1 + ncb), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
+            hipLaunchKernelGGL(k2_fused_t<false>, dim3(1 + ncb), dim3(K2T), h->k2_lds, s, h->P, h->members, 0, nv0, 0, h->fcount, h->flocal, (int)(h->k2_lds / 8), h->E[1 - h->ecur], 0,
                                h->ne_dev, h->totals + 2, h->k2mail_d + (slotB - 2), seqB, h->k2dbg, (const CutDev *)cd, h->abort_d, h->EP[1 - h->ecur],
-                               hn, h->counters + CSTRIDE * std::max(spec_ns, 0), h->zlist + ZMAX * std::max(spec_ns, 0));
+                               hn, h->counters + CSTRIDE * std::max(spec_ns, 0), h->zlist + ZMAX * std::max(spec_ns, 0), K2V2{});
         }
         auto tl3 = std::chrono::steady_clock::now();
         HIP_TRY(hipGetLastError());
@@ -2677,8 +2769,8 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         if (nm >= 2) {
             if (nm <= K2_MAXNM) {
                 const int sq = ++h->mailseq, sl = 2 + (h->k2flip ^= 1);
-                hipLaunchKernelGGL(k2_fused, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, h->fcount, h->flocal,
-                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->k2mail_d + (sl - 2), sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d, h->EP[h->ecur], hn, (int *)nullptr, (int *)nullptr);
+                hipLaunchKernelGGL(k2_fused_t<false>, dim3(1), dim3(K2T), h->k2_lds, s, h->P, h->members, nzero, nv0, ncross, h->fcount, h->flocal,
+                                   (int)(h->k2_lds / 8), h->E[h->ecur], h->ne, h->ne_dev, h->totals + 2, h->k2mail_d + (sl - 2), sq, h->k2dbg, (const CutDev *)nullptr, h->abort_d, h->EP[h->ecur], hn, (int *)nullptr, (int *)nullptr, K2V2{});
                 HIP_TRY(hipGetLastError());
                 h->pend_k2 = true; h->pend_seq = sq; h->pend_slot = sl; h->pend_ebase = h->ne;
                 h->pend_nm = nm; h->pend_len_ub = len_ub; h->pend_nzero = nzero; h->pend_nv0 = nv0; h->pend_ncross = ncross;
@@ -2735,7 +2827,7 @@ static int hot_begin(bslv_poly *h, const int *tc)
     h->P.hv = h->hv_d; h->P.nhv = nhv; h->P.nv_base = nv;
     {   // membership bitmaps of the hot elements with long lists; ranks up to those this chunk can add
         constexpr int LMAX = 64;
-        const int stride = ((int)h->facet_of_rank.size() + 1024 + 63) / 32;
+        const int stride = ((int)h->facet_of_rank.size() + h->chunk_cuts + 1024 + 63) / 32;
         const size_t need = (size_t)LMAX * stride;
         if (need > h->lbitscap) { const size_t nc = std::max(need, h->lbitscap * 2); if ((rc = grow(&h->lbits_d, 0, nc, s))) return rc; h->lbitscap = nc; }
         if (!h->lnslots_d && (rc = grow(&h->lnslots_d, 0, 4, s))) return rc;
@@ -2788,6 +2880,7 @@ static int hot_end(bslv_poly *h)
 }
 
 #include "poly_rounds_host.inc"
+#include "poly_rounds2_host.inc"
 
 static int upload_initial(bslv_poly *h, const std::vector<double> &X /* (d+1) x d */, const std::vector<std::vector<int>> &inc)
 {
@@ -2871,13 +2964,18 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     }
     // k2_fused keeps the local incidence bit matrix in LDS: ask for most of the CU's 160 KB, settle for 48 KB
     h->k2_lds = 128 * 1024;
-    if (hipFuncSetAttribute((const void *)k2_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)k2_fused_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k2_fused_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess) {
         (void)hipGetLastError();
         h->k2_lds = 48 * 1024;
     }
     if (const char *cl = getenv("BSLV_CUT_LOG")) h->cutlog = fopen(cl, "w");
     if (getenv("BSLV_NO_SPEC")) h->speculate = false;
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
+    if (getenv("BSLV_NO_ROUNDS2")) h->rounds2_enabled = false;
+    if (const char *e = getenv("BSLV_CHUNK_CUTS")) h->chunk_cuts = std::min(4096, std::max(32, atoi(e)));
+    if (const char *e = getenv("BSLV_R2_MIN_CUTS")) h->r2_min_cuts = std::max(-1, atoi(e));
+    if (const char *e = getenv("BSLV_R2_RULE")) h->r2_rule = atoi(e) ? 1 : 0;
     if (const char *e = getenv("BSLV_CROSS_UB")) h->cross_ub = std::max(0, atoi(e));
     if (const char *e = getenv("BSLV_K2_LDS")) h->k2_lds = (size_t)std::max(64, atoi(e));      // test hook: a small value forces the multi-kernel prune
     if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
@@ -2914,6 +3012,7 @@ void bslv_poly_destroy(bslv_poly *h)
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
     fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
+    if (h->rounds2) { rounds2_free(*h->rounds2); delete h->rounds2; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
     if (h->counters_h) (void)hipHostFree(h->counters_h);
     if (h->mail_h) (void)hipHostFree((void *)h->mail_h);
@@ -3190,6 +3289,9 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 2: h->hot_enabled = value != 0; return 0;
     case 3: h->cross_ub = (int)std::max(0L, value); return 0;
     case 4: h->fm_min = (int)std::max(2L, value); return 0;
+    case 6: h->rounds2_enabled = value != 0; return 0;                  /* device-selected rounds of independent cuts inside a hot chunk */
+    case 7: h->chunk_cuts = (int)std::min(4096L, std::max(32L, value)); return 0;    /* cuts classified and applied together */
+    case 8: h->r2_min_cuts = (int)std::max(-1L, value); return 0;        /* rounds go on while they average at least this many cuts (0: until every round holds one cut, -1: always) */
     case 5: h->member_lists = value != 0; return 0;                     /* edges of large facets confirmed through member lists (1) or against all elements (0) */           /* facets from this size on confirm edges through the facet-major member lists (4096) */
     default: return BSLV_E_ARG;
     }
@@ -3201,6 +3303,14 @@ int bslv_poly_path_stats(const bslv_poly *h, long out[6])
     return 0;
 }
 long bslv_poly_conflict_pairs(const bslv_poly *h) { return h ? h->conf_pairs : 0; }
+// device-selected rounds inside hot chunks: out[0] rounds, [1] cuts applied in them, [2] chunks, [3] prunes that went through the
+// multi-kernel path, [4] rounds taken back for want of capacity
+int bslv_poly_rounds2_stats(const bslv_poly *h, long out[5])
+{
+    if (!h || !out) return BSLV_E_ARG;
+    out[0] = h->r2_rounds; out[1] = h->r2_cuts; out[2] = h->r2_chunks; out[3] = h->r2_fallback_prunes; out[4] = h->r2_declined;
+    return 0;
+}
 // MEASUREMENT ONLY (bench / profiles): turns the engine into nv synthetic live points so that the
 // batched incidence kernel can be timed at sizes beyond the caches.  The polyhedron is destroyed.
 int bslv_poly_bench_fill(bslv_poly *h, int nv, unsigned long long seed)

@@ -96,6 +96,12 @@ class PolyEngine:
     def debug_set(self, key, value):
         check(self.lib.bslv_poly_debug_set(self.h, int(key), int(value)))
 
+    def rounds2_stats(self):
+        out = (ctypes.c_long * 5)()
+        self.lib.bslv_poly_rounds2_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        check(self.lib.bslv_poly_rounds2_stats(self.h, out))
+        return dict(rounds=out[0], cuts=out[1], chunks=out[2], fallback_prunes=out[3], declined=out[4])
+
     def path_stats(self):
         out = (ctypes.c_long * 6)()
         check(self.lib.bslv_poly_path_stats(self.h, out))

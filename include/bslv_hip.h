@@ -133,8 +133,13 @@ long bslv_poly_rounds_run(const bslv_poly *h);
 int  bslv_poly_path_stats(const bslv_poly *h, long out[6]);
 /* test hook, same switches as the BSLV_* environment variables but at run time: key 0 dynamic LDS bytes of the one-workgroup
  * prune (64 forces the multi-kernel prune), 1 speculative launch on/off, 2 hot mode on/off, 3 CROSS_UB, 4 size of a new facet
- * from which the multi-kernel prune builds facet-major member lists (default 4096) */
+ * from which the multi-kernel prune builds facet-major member lists (default 4096), 5 member lists on/off, 6 device-selected
+ * rounds of independent cuts inside a hot chunk on/off, 7 cuts per chunk (32..4096, default 512) */
 int  bslv_poly_debug_set(bslv_poly *h, int key, long value);
+/* rounds of independent cuts chosen and applied on the device inside a hot chunk (debug_set key 6 switches them off, key 7 sets
+ * the number of cuts classified and applied together): out[0] rounds, [1] cuts applied in them, [2] chunks, [3] prunes that took
+ * the multi-kernel path, [4] rounds taken back for want of capacity */
+int  bslv_poly_rounds2_stats(const bslv_poly *h, long out[5]);
 int  bslv_poly_init(bslv_poly *h, int *rc_out);               /* poly__intl_apprx :153 */
 int  bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out); /* poly__get_vrtx :210 */
 int  bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count);

@@ -134,6 +134,30 @@ def main():
         print("rule (%s): %d conflict pairs of %d, greedy independent set %d, rounds (static upper bound) %d; local-minima rule: first set %d, rounds %d" % (
             name, len(pairs), C * (C - 1) // 2, greedy(C, pairs), rounds(C, pairs), sum(1 for x in lvl if x == 1), dp))
         if name == "a":
+            rng = np.random.default_rng(1)
+            nb = [[] for _ in range(C)]
+            for x, y in pairs:
+                nb[x].append(y); nb[y].append(x)
+            deg = np.array([len(v) for v in nb])
+            print("   degree: mean %.1f max %d" % (deg.mean(), deg.max()))
+            for label, mk in (("fixed random priority", lambda r, alive: pri0), ("fresh random priority per round", lambda r, alive: rng.permutation(C)),
+                              ("smallest remaining degree first (ties: index)", None)):
+                pri0 = rng.permutation(C)
+                alive = np.ones(C, bool)
+                r = 0
+                sizes = []
+                while alive.any():
+                    if mk is None:
+                        dg = np.array([sum(1 for o in nb[k] if alive[o]) for k in range(C)])
+                        pri = dg * C + np.arange(C)
+                    else:
+                        pri = mk(r, alive)
+                    sel = [k for k in range(C) if alive[k] and all((not alive[o]) or pri[o] > pri[k] for o in nb[k])]
+                    for k in sel:
+                        alive[k] = False
+                    sizes.append(len(sel))
+                    r += 1
+                print("   local minima under %s: %d rounds, first sets %s" % (label, r, sizes[:6]))
             tcs = tc[hot].astype(np.int64)
             ev = sum(int(tc[u]) * int(tc[v]) for u, v in Eh)
             print("   pair enumerations: elements %d, hot-hot edges %d (%d edges)" % ((tcs * (tcs - 1) // 2).sum(), ev, len(Eh)))

@@ -13,7 +13,7 @@ from test_poly_gpu import assert_slotwise_equal
 
 pytestmark = pytest.mark.gpu
 
-HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS"]
+HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS"]
 MODES = {
     "default": {},
     "no_spec": {"BSLV_NO_SPEC": "1"},
@@ -104,11 +104,13 @@ def test_chunk_modes_agree_bitwise(q, N, seed):
     default.  Every hook combination must give the dump of the default mode bit for bit, and the same polyhedron
     as the oracle."""
     D = np.vstack([ph.tangent_halfspaces(q, q + 3, seed), clustered_halfspaces(q, N, seed, 0.05)])
-    ref_rc, ref = gpu_run({}, q, D, q + 3, 1, 128)
+    # (the device-selected rounds inside hot chunks apply the cuts in another order -- same sets, other slot numbers: they
+    # have their own test below; here every mode runs the single-cut pipeline)
+    ref_rc, ref = gpu_run({"BSLV_NO_ROUNDS2": "1"}, q, D, q + 3, 1, 128)
     for name, env in MODES.items():
         if name == "default":
             continue
-        rc, d = gpu_run(env, q, D, q + 3, 1, 128)
+        rc, d = gpu_run(dict(env, BSLV_NO_ROUNDS2="1"), q, D, q + 3, 1, 128)
         assert rc == ref_rc, name
         for key in ("pu", "pi", "ps", "X", "du", "di", "Y", "E", "I", "DE"):
             assert np.array_equal(d[key], ref[key]), (name, key)
@@ -120,6 +122,66 @@ def test_chunk_modes_agree_bitwise(q, N, seed):
     do = O.dump()
     O.close()
     ph.assert_same(ph.canonical(do), ph.canonical(ref))
+
+
+R2_MODES = {
+    "rounds always": {"BSLV_R2_MIN_CUTS": "-1"},
+    "rounds, default stop rule": {},
+    "rounds, small chunks": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_CHUNK_CUTS": "64"},
+    "rounds, every prune through the multi-kernel path": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_K2_LDS": "64"},
+    "rounds without speculation in the tail": {"BSLV_NO_SPEC": "1"},
+}
+
+
+def _r2_cases():
+    import itertools
+    cases = []
+    for q, N, seed in [(3, 600, 41), (4, 300, 42), (5, 250, 43), (6, 70, 44)]:
+        cases.append(("tangent q%d" % q, q, np.vstack([ph.tangent_halfspaces(q, q + 3, seed), ph.tangent_halfspaces(q, N, seed + 100)]), q + 3))
+    for q, N, seed in [(4, 300, 45), (5, 200, 46)]:
+        cases.append(("crowded q%d" % q, q, np.vstack([ph.tangent_halfspaces(q, q + 3, seed), clustered_halfspaces(q, N, seed, 0.05)]), q + 3))
+    for q in (4, 5):
+        # degenerate: a cube, then many cuts through its vertices and edges (on-plane elements, redundant cuts, ties)
+        cube = np.vstack([np.eye(q), -np.eye(q)])
+        signs = np.array(list(itertools.product([-1, 1], repeat=q)), float)
+        extra = np.vstack([signs / (q - 1), signs / (q - 2), signs / q, cube * 1.5, cube[::-1] * 1.25])
+        cases.append(("truncated cube q%d" % q, q, np.vstack([cube, extra]), 2 * q))
+    return cases
+
+
+@pytest.mark.parametrize("case", _r2_cases(), ids=lambda c: c[0])
+def test_rounds_of_independent_cuts_build_the_same_polyhedron(case):
+    """poly_rounds2: inside a hot chunk the device picks rounds of mutually independent cuts (local minima of a shuffled
+    order) and applies each round in the passes of one cut.  Independent cuts commute, so the result must be the polyhedron
+    of the sequential definition: vertices, facets, incidence, adjacency and dual adjacency equal the oracle's as sets
+    (coordinates 1e-9), and the same cuts are found redundant -- with rounds to the end, with the default stop rule (the tail
+    goes through the single-cut pipeline), with small chunks, and with every prune forced through the multi-kernel path."""
+    name, q, D, k0 = case
+    O = ph.FlatPoly("oracle", q, 0, None)
+    rco = ph.run_sequence(O, D, None, k0)
+    O.dual_adjacency()
+    exp = ph.canonical(O.dump())
+    O.close()
+    for mode, env in R2_MODES.items():
+        with hooks(env):
+            G = PolyEngine(q, 0, None)
+            rcs = [G.add(D[i], 0) for i in range(k0)]
+            assert G.init() == 0
+            rcs += list(G.add_cuts(D[k0:], None))
+            G.dual_adjacency()
+            got = ph.canonical(G.dump())
+            st = G.rounds2_stats()
+            G.close()
+        assert st["cuts"] > 0 and st["rounds"] > 0, (mode, st)
+        if "multi-kernel" in mode:
+            assert st["fallback_prunes"] > 0, (mode, st)
+        if mode == "rounds always":
+            assert st["cuts"] + sum(rcs[k0:]) == len(D) - k0, (mode, st)          # every cut applied in a round or found redundant
+        # (which cuts come back 'redundant' depends on the order: of two cuts through the same corner the shallower one is
+        # redundant only when the deeper one went first; the facets that carry a vertex at the end are the same)
+        if name.startswith("tangent"):
+            assert sum(rcs) == sum(rco), (mode, sum(rcs), sum(rco))
+        ph.assert_same(got, exp)
 
 
 def _smid_cut_sequence(steps):
@@ -180,12 +242,27 @@ def test_smid_benson_steps_identical_in_all_modes():
     """the batched driver on the bench workload: default mode, everything conservative, every prune through the fallback
     (which exercises the abort / decline / rerun machinery on every cut) -- the same polyhedron bit for bit"""
     dumps = {}
-    for name, env in (("default", {}), ("conservative", {"BSLV_NO_SPEC": "1", "BSLV_NO_HOT": "1"}), ("fallback_prune", {"BSLV_K2_LDS": "64"})):
+    for name, env in (("default", {"BSLV_NO_ROUNDS2": "1"}), ("conservative", {"BSLV_NO_SPEC": "1", "BSLV_NO_HOT": "1"}),
+                      ("fallback_prune", {"BSLV_K2_LDS": "64", "BSLV_NO_ROUNDS2": "1"}), ("rounds", {"BSLV_R2_MIN_CUTS": "-1"})):
         with hooks(env):
             dumps[name] = _smid_cut_sequence(5)[3]
     for name in ("conservative", "fallback_prune"):
         for key in ("pu", "pi", "ps", "X", "du", "di", "Y", "E", "I"):
             assert np.array_equal(dumps[name][key], dumps["default"][key]), (name, key)
+    # the device-selected rounds apply the cuts of a batch in another order, which changes the vertices the next batch starts
+    # from: a different (equally valid) run of the algorithm.  It must be a consistent polyhedron: every vertex satisfies every
+    # cut, lies on at least q facets and on exactly those its incidence list names
+    d = dumps["rounds"]
+    q = d["d"]
+    live = d["pu"].astype(bool) & (d["pi"] == 0)
+    Y = d["Y"][d["du"].astype(bool) & (d["di"] == 0)]
+    w = np.hstack([Y[:, :-1], 1 - Y[:, :-1].sum(axis=1, keepdims=True)])
+    assert (d["X"][live] @ w.T - Y[:, -1][None, :]).min() > -1e-7
+    cnt = np.bincount(d["I"][:, 0], minlength=len(live))
+    assert cnt[live].min() >= q
+    Yall = d["Y"]; wall = np.hstack([Yall[:, :-1], 1 - Yall[:, :-1].sum(axis=1, keepdims=True)])
+    I = d["I"][live[d["I"][:, 0]] & (d["di"][d["I"][:, 1]] == 0)]
+    assert np.abs(np.einsum("ij,ij->i", d["X"][I[:, 0]], wall[I[:, 1]]) - Yall[I[:, 1], -1]).max() < 1e-6
 
 
 def _host_edge_test_sample(d, npairs, seed):
