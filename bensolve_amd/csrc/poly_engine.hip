@@ -1782,7 +1782,9 @@ __global__ __launch_bounds__(K2T) void k2_fused_t(PolyView P, int *members, int 
         }
         nm = s_base;
         if (nm > K2_MAXNM) { v2_result(-1, nm); return; }          // too large for one workgroup: multi-kernel prune
-        k2v2_check_members(V, vs, s_mem, nm, members, nzero);
+#ifdef BSLV_R2_CHECK_MEMBERS
+        k2v2_check_members(V, vs, s_mem, nm, members, nzero);          // debugging aid, O(nm^2): a member list never holds an element twice
+#endif
         if (tid == 0 && nm >= 2) atomicAdd((unsigned long long *)V.pair_tests, (unsigned long long)((long long)nm * (nm - 1) / 2));
         if (nm < 2) { v2_result(0, nm); return; }
     }
