@@ -67,6 +67,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+        # the data-path collective is the library's own: direct ncclAllGather (RCCL over xGMI) inside bslv_benson_step_dist;
+        # torch.distributed hands out the communicator id and does the barrier / max-over-ranks of the timing
+        from bensolve_amd.benson import dist_init_rccl
+        dist_init_rccl(dist, device)
 
     if args.steps is None:
         args.steps = 3 if args.workload == "S-degenerate" else 8
@@ -97,7 +101,9 @@ def main():
 
     def one_step():
         if world > 1:
-            return eng.step_distributed(B * world, dist, device)
+            s = eng.step(B * world)              # (bslv_benson_step_dist: collect -> this rank's LPs -> all-gather -> apply)
+            s.update(n_total=s["lps"])
+            return s
         if pipe is not None:
             s = pipe.step()
             s["lps"] = s["lps_solved"]
@@ -270,7 +276,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s (q=%d, n=%d, m=%d dense covering VLP, seed per SURVEY 8d)" % (args.workload, q, n, m),
                        "lp_rows_cols": [dims["M"], dims["N"]], "rows_folded_by_presolve": dims["rows_folded"], "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": "vertex batch sharded over %d GPU(s), one all_gather of cut records per step" % world,
+                       "parallelism": "vertex batch sharded over %d GPU(s), one ncclAllGather of cut records per step (in the library), cut application replicated" % world,
                        "lp_poly_overlap": pipe is not None,
                        "tableau_slot_bytes": slot_bytes, "pool_slots": pool_slots, "batch_policy": args.policy or 1, "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
@@ -281,6 +287,8 @@ def main():
         print(json.dumps(out))
     eng.close()
     if world > 1:
+        from bensolve_amd.benson import dist_finalize
+        dist_finalize()
         dist.destroy_process_group()
 
 

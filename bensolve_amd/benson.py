@@ -181,6 +181,54 @@ class BensonEngine:
         return st
 
 
+def dist_init_rccl(dist, device):
+    """Join the library's own RCCL communicator (include/bslv_hip.h section 4a): rank 0 creates the ncclUniqueId, ONE
+    broadcast over `dist` (torch.distributed, any backend) hands it to the others; from then on BensonEngine.step() runs the
+    exchange step inside libbslv_hip.so (bslv_benson_step_dist: direct ncclAllGather over xGMI)."""
+    import torch
+    lib = load_library()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    buf = (ctypes.c_ubyte * 128)()
+    if rank == 0:
+        check(lib.bslv_dist_unique_id(buf, 128))
+    t = torch.tensor(list(buf), dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=0)
+    idb = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+    check(lib.bslv_dist_init(rank, world, idb, 128))
+
+
+_cb_keep = []
+
+
+def dist_init_callback(dist):
+    """The same exchange step over a caller-supplied all-gather (here: torch.distributed, e.g. gloo): for tests on a one-GPU
+    box, where RCCL refuses two ranks on one device."""
+    import torch
+    lib = load_library()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_void_p)
+
+    def gather(send, recv, count, ctx):
+        try:
+            a = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)).copy())
+            out = [torch.empty_like(a) for _ in range(world)]
+            dist.all_gather(out, a)
+            np.ctypeslib.as_array(recv, shape=(count * world,))[:] = torch.cat(out).numpy()
+            return 0
+        except Exception:
+            return 1
+    cb = FN(gather)
+    _cb_keep.append(cb)
+    lib.bslv_dist_init_callback.argtypes = [ctypes.c_int, ctypes.c_int, FN, ctypes.c_void_p]
+    check(lib.bslv_dist_init_callback(rank, world, cb, None))
+
+
+def dist_finalize():
+    lib = load_library()
+    lib.bslv_dist_finalize.restype = None
+    lib.bslv_dist_finalize()
+
+
 class PipelinedStepper:
     """Single-process software pipeline: the LPs of batch k (LP engine, second host thread; ctypes releases
     the GIL) overlap with the cut application of batch k-1 (polyhedron engine).  Batch members are marked

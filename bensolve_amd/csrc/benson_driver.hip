@@ -587,6 +587,8 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
 int bslv_benson_step(bslv_benson *h, int max_batch, long *stats, double *ms)
 {
     if (!h) return BSLV_E_ARG;
+    // more than one rank (bslv_dist_init): the batch is dealt to the ranks and the records are exchanged (dist.hip)
+    if (bslv_dist_world() > 1) return bslv_benson_step_dist(h, max_batch, stats, ms);
     auto t0 = clk::now();
     int nl = 0, nt = 0, rc;
     if ((rc = bslv_benson_collect(h, max_batch, 0, 1, &nl, &nt))) return rc;

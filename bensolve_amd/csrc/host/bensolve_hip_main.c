@@ -28,6 +28,59 @@ static void usage(void)
            );
 }
 
+/* Multi-GPU launch (one process per GPU; RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT as torchrun, mpirun wrappers
+ * or a shell loop set them): rank 0 creates the RCCL id and hands it to the other ranks over TCP (port MASTER_PORT + 17, or
+ * BSLV_BOOT_PORT), then every rank joins the communicator.  Returns the world size, or -1 on failure. */
+#include <sys/socket.h>
+#include <netinet/in.h>
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <unistd.h>
+static int env_int(const char *k, int dflt) { const char *v = getenv(k); return v && *v ? atoi(v) : dflt; }
+static int dist_bootstrap(int *rank_out)
+{
+    const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0), local = env_int("LOCAL_RANK", rank);
+    *rank_out = rank;
+    if (world <= 1) return 1;
+    if (bslv_set_device(local)) { printf("rank %d: cannot use GPU %d: %s\n", rank, local, bslv_last_error()); return -1; }
+    const char *addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1";
+    const int port = getenv("BSLV_BOOT_PORT") ? atoi(getenv("BSLV_BOOT_PORT")) : env_int("MASTER_PORT", 29500) + 17;
+    unsigned char id[128];
+    if (rank == 0) {
+        if (bslv_dist_unique_id(id, 128)) { printf("rank 0: %s\n", bslv_last_error()); return -1; }
+        int ls = socket(AF_INET, SOCK_STREAM, 0), one = 1;
+        setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+        struct sockaddr_in sa; memset(&sa, 0, sizeof sa);
+        sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons((unsigned short)port);
+        if (ls < 0 || bind(ls, (struct sockaddr *)&sa, sizeof sa) || listen(ls, world)) { printf("rank 0: cannot listen on port %d\n", port); return -1; }
+        for (int k = 1; k < world; k++) {
+            int c = accept(ls, NULL, NULL);
+            if (c < 0 || write(c, id, 128) != 128) { printf("rank 0: handing out the communicator id failed\n"); return -1; }
+            close(c);
+        }
+        close(ls);
+    } else {
+        struct addrinfo hints, *res = NULL; memset(&hints, 0, sizeof hints);
+        hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+        char ps[16]; snprintf(ps, sizeof ps, "%d", port);
+        if (getaddrinfo(addr, ps, &hints, &res) || !res) { printf("rank %d: cannot resolve %s\n", rank, addr); return -1; }
+        int c = -1, got = 0;
+        for (int tries = 0; tries < 600 && got != 128; tries++) {          /* rank 0 may not be listening yet: retry for a minute */
+            c = socket(AF_INET, SOCK_STREAM, 0);
+            if (c >= 0 && connect(c, res->ai_addr, res->ai_addrlen) == 0) {
+                got = 0;
+                while (got < 128) { ssize_t r = read(c, id + got, 128 - got); if (r <= 0) break; got += (int)r; }
+            }
+            if (c >= 0) close(c);
+            if (got != 128) usleep(100000);
+        }
+        freeaddrinfo(res);
+        if (got != 128) { printf("rank %d: no communicator id from %s:%d\n", rank, addr, port); return -1; }
+    }
+    if (bslv_dist_init(rank, world, id, 128)) { printf("rank %d: %s\n", rank, bslv_last_error()); return -1; }
+    return world;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2 || argv[1][0] == '-') { usage(); return 1; }
@@ -58,6 +111,18 @@ int main(int argc, char **argv)
     }
     if (!base[0]) { snprintf(base, sizeof base, "%s", file); char *dot = strchr(base, '.'); if (dot && dot != base) *dot = 0; }
     if (batch < 1) batch = 1;
+    int rank = 0;
+    const int world = dist_bootstrap(&rank);
+    if (world < 0) return 3;
+    if (world > 1) {
+        if (presol) { if (rank == 0) printf("option -s is not available with more than one rank (the pre-images stay with the rank that solved the LP)\n"); return 1; }
+        if (rank != 0) {                              /* one rank talks; the others write their (identical) replica under <base>.rank<k> */
+            msg = 0;
+            char tmp[1024];
+            snprintf(tmp, sizeof tmp, "%s", base);
+            snprintf(base, sizeof base, "%.1000s.rank%d", tmp, rank);
+        }
+    }
 
     bslv_vlp *v = NULL;
     int line = 0;
@@ -145,5 +210,6 @@ int main(int argc, char **argv)
     if (lower) bslv_poly_destroy(lower);
     bslv_vlp_info_free(&info);
     bslv_vlp_free(v);
+    if (world > 1) bslv_dist_finalize();
     return 0;
 }

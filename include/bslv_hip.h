@@ -226,6 +226,27 @@ bslv_poly *bslv_benson_poly(bslv_benson *h);
 bslv_lpq  *bslv_benson_lp(bslv_benson *h);
 
 /* ------------------------------------------------------------------------------------------
+ * 4a. Multi-GPU: one process per GPU, one exchange step per outer iteration, in the library.
+ *     bslv_set_device(LOCAL_RANK), then either bslv_dist_init with the 128-byte ncclUniqueId of rank 0 (RCCL over xGMI; the
+ *     host side distributes the id: bensolve_hip over TCP to MASTER_ADDR:MASTER_PORT, bench.py with one broadcast), or
+ *     bslv_dist_init_callback with an all-gather of the caller (tests on a one-GPU box, where RCCL refuses two ranks on one
+ *     device).  From then on bslv_benson_step -- and with it bslv_vlp_solve_primal and the command-line driver -- runs
+ *     bslv_benson_step_dist: the vertex batch is dealt to the ranks (bslv_benson_collect), every rank solves its shard, ONE
+ *     all-gather of fixed-size record blocks, every rank applies all records in ascending source slot, so the replicas of
+ *     the polyhedron stay bit-identical.  The reference has no counterpart (single process, bslv_algs.c:1030-1080).
+ * ------------------------------------------------------------------------------------------ */
+typedef int (*bslv_allgather_fn)(const double *send, double *recv, int count_per_rank, void *ctx);   /* 0 = ok */
+int  bslv_dist_unique_id(unsigned char *out, int len /* >= 128 */);          /* rank 0: ncclGetUniqueId */
+int  bslv_dist_init(int rank, int world, const unsigned char *id, int len);  /* ncclCommInitRank on the current device */
+int  bslv_dist_init_callback(int rank, int world, bslv_allgather_fn fn, void *ctx);
+void bslv_dist_finalize(void);
+int  bslv_dist_rank(void);
+int  bslv_dist_world(void);
+int  bslv_dist_allgather(const double *send, double *recv, int count_per_rank);   /* host buffers; recv holds world * count */
+int  bslv_dist_stats(long *gathers, double *ms);
+int  bslv_benson_step_dist(bslv_benson *h, int max_batch_global, long *stats /* 8 */, double *ms /* 3 */);
+
+/* ------------------------------------------------------------------------------------------
  * 4b. The callers around phase 2: ordering cone data (sol_init, bslv_vlp.c:599-864), cone_vertenum
  *     (bslv_algs.c:331-407), phase 0 (bslv_algs.c:673-800), phase 1 of the primal algorithm (bslv_algs.c:811-933) and the
  *     sequence of bslv_main.c:236-345.  Matrices of generators are q x k row-major with the generators as columns
