@@ -160,7 +160,7 @@ int main(int argc, char **argv)
     long cnt[4], lps = 0, cuts = 0, piv = 0;
     if ((rc = bslv_sol_write3(dual2 ? lower : bslv_benson_poly(h), base, ".sol", dual2, info.negate_primal, info.negate_dual_last, cnt))) { printf("writing results failed (%d): %s\n", rc, bslv_last_error()); return 3; }
     if (presol && h && (rc = bslv_sol_write_preimages(h, base, ".sol", v->m, v->n, v->optdir, info.c_dir))) { printf("writing the pre-images failed (%d): %s\n", rc, bslv_last_error()); return 3; }
-    if (presol && !h) printf("option -s is implemented for the primal algorithm in phase 2 only: no pre-image files\n");
+    if (presol && lower && (rc = bslv_sol_write_preimages_dual(lower, base, ".sol", v->m, v->n, v->optdir, info.c_dir))) { printf("writing the pre-images failed (%d): %s\n", rc, bslv_last_error()); return 3; }
     if (h) bslv_benson_totals(h, &lps, &cuts, &piv);
     {   /* <name>.log, fields and layout of bslv_main.c:346-397 */
         char lfile[1100];
@@ -207,7 +207,7 @@ int main(int argc, char **argv)
     if (msg >= 2) printf("outer iterations %ld, phase-2 cuts %ld, phase-2 pivots %ld; upper image: %ld points, %ld directions; lower image: %ld points, %ld directions\n",
                          info.steps, cuts, piv, cnt[0], cnt[1], cnt[2], cnt[3]);
     if (h) bslv_benson_destroy(h);
-    if (lower) bslv_poly_destroy(lower);
+    if (lower) { bslv_dual_preimages_free(lower); bslv_poly_destroy(lower); }
     bslv_vlp_info_free(&info);
     bslv_vlp_free(v);
     if (world > 1) bslv_dist_finalize();

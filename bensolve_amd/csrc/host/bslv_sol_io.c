@@ -177,3 +177,40 @@ int bslv_sol_write_preimages(bslv_benson *eng, const char *base, const char *suf
     free(pu); free(pi); free(du); free(di); free(X); free(Y); free(row);
     return 0;
 }
+
+/* option -s with the dual algorithm (poly_output(..., SWAP, ...) with PRE_IMG_ON, bslv_algs.c:1566-1573): the polyhedron holds the
+ * lower image on its primal side.  <base>_pre_img_p: x of every element of the upper image (dual slots, ascending);
+ * <base>_pre_img_d: (u, w) of every vertex of the lower image (primal elements, ascending), zeros for its directions (:1540-1546). */
+int bslv_sol_write_preimages_dual(bslv_poly *poly, const char *base, const char *suffix, int m, int n, int optdir, int c_dir)
+{
+    const int d = bslv_poly_dim(poly), nv = bslv_poly_nprimal(poly), nf = bslv_poly_ndual(poly);
+    unsigned char *pu = (unsigned char *)malloc(nv + 1), *pi = (unsigned char *)malloc(nv + 1);
+    unsigned char *du = (unsigned char *)malloc(nf + 1), *di = (unsigned char *)malloc(nf + 1);
+    int rc;
+    if ((rc = bslv_poly_get_primal(poly, pu, pi, NULL, NULL)) || (rc = bslv_poly_get_dual(poly, du, di, NULL))) return rc;
+    char path[1024];
+    double *row = (double *)malloc((size_t)(m + n + d + 1) * sizeof(double));
+    snprintf(path, sizeof path, "%s_pre_img_p%s", base, suffix);
+    FILE *f = fopen(path, "w");
+    if (!f) return BSLV_E_ARG;
+    for (int k2 = 0; k2 < nf; k2++) {
+        if (!du[k2]) continue;
+        if (bslv_dual_preimage_x(poly, k2, row)) for (int k = 0; k < n; k++) row[k] = 0.0;
+        for (int k = 0; k < n; k++) fprintf(f, k ? " %.14g" : "%.14g", row[k]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    snprintf(path, sizeof path, "%s_pre_img_d%s", base, suffix);
+    f = fopen(path, "w");
+    if (!f) return BSLV_E_ARG;
+    for (int i = 0; i < nv; i++) {
+        if (!pu[i]) continue;
+        if (pi[i] || bslv_dual_preimage_uw(poly, i, row)) for (int k = 0; k < m + d; k++) row[k] = 0.0;
+        else { for (int k = 0; k < m; k++) row[k] *= optdir; for (int k = 0; k < d; k++) row[m + k] *= c_dir; }
+        for (int k = 0; k < m + d; k++) fprintf(f, k ? " %.14g" : "%.14g", row[k]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    free(pu); free(pi); free(du); free(di); free(row);
+    return 0;
+}

@@ -9,6 +9,7 @@
 #include <vector>
 #include <deque>
 #include <unordered_map>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 
@@ -290,7 +291,19 @@ static int phase1_primal(const Problem &pb, Sol &S, double eps_phase1, double ep
 //      status: 0 ok, 1 VLP_INFEASIBLE, 2 VLP_UNBOUNDED.  The polyhedron (primal side = lower image) is handed to the caller. ----
 //      hom != 0: the homogeneous problem of phase1_dual (:1248-1371; init_P1(..., HOMOGENEOUS): bounds zeroed, one more row
 //      eta.y <= 1), started with the mean of the columns of Z and the generators Y of the ordering cone as directions.
-static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int batch, bslv_poly **poly_out, int *status, long *lps, long *steps)
+// option -s with the dual algorithm (phase2_dual with opt->solution == PRE_IMG_ON, bslv_algs.c:1388-1389, 1431-1432, 1488-1546):
+// x (n values) of every vertex of the UPPER image -- a cut of the lower image, i.e. a dual slot of the polyhedron -- and
+// (u, w) (m + q values) of every confirmed vertex of the LOWER image (a primal element)
+struct DualPreimg {
+    int m = 0, n = 0, q = 0;
+    std::unordered_map<int, std::vector<double>> x_by_facet, uw_by_element;
+    std::vector<std::pair<std::vector<double>, std::vector<double>>> start;       // (y, x) of PART 1, until the dual slots exist
+};
+static std::mutex g_dpre_mu;
+static std::unordered_map<const bslv_poly *, DualPreimg *> g_dpre;
+
+static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int batch, bslv_poly **poly_out, int *status, long *lps, long *steps,
+                       DualPreimg *store = nullptr)
 {
     *status = 0; *poly_out = nullptr;
     const int m = pb.m, n = pb.n, q = pb.q, M = m + q + (hom ? 1 : 0), N = n + q;
@@ -333,6 +346,11 @@ static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int
     if (st != BSLV_LP_OPTIMAL) { *status = st == BSLV_LP_INFEASIBLE ? 1 : 2; bslv_poly_destroy(poly); poly = nullptr; return done(0); }
     ++*lps;
     if ((rc = bslv_lpq_get_primal(lp, 1, &zero, M + n, q, y.data()))) return done(rc);
+    if (store) {                                                                     // x of the first vertex (:1431-1432)
+        std::vector<double> x(n);
+        if ((rc = bslv_lpq_get_primal(lp, 1, &zero, M, n, x.data()))) return done(rc);
+        store->start.emplace_back(y, x);
+    }
     int prc;
     if ((rc = bslv_poly_add(poly, y.data(), 0, &prc))) return done(rc);
     for (int j = 0; j < nd0; j++) {                                                  // the (recession | ordering) cone's generators as directions
@@ -342,6 +360,21 @@ static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int
     int irc = 0;
     if ((rc = bslv_poly_init(poly, &irc))) return done(rc);
     if (irc) { set_error("phase 2 (dual): initial outer approximation failed (bslv_poly.c:174)"); return done(BSLV_E_STATE); }
+    if (store) {
+        // poly__intl_apprx re-adds queued halfspaces as new dual slots (bslv_poly.c:190-197): find the first vertex by its coordinates
+        const int nd = bslv_poly_ndual(poly);
+        std::vector<unsigned char> du(nd), di(nd);
+        std::vector<double> dc((size_t)nd * q);
+        if ((rc = bslv_poly_get_dual(poly, du.data(), di.data(), dc.data()))) return done(rc);
+        for (int f = 0; f < nd; f++) {
+            if (!du[f] || di[f]) continue;
+            for (auto &sp : store->start) {
+                double dd = 0;
+                for (int k = 0; k < q; k++) dd = std::max(dd, std::fabs(sp.first[k] - dc[(size_t)f * q + k]));
+                if (dd <= 1e-12 * (1.0 + std::fabs(sp.first[q - 1]))) { store->x_by_facet[f] = sp.second; break; }
+            }
+        }
+    }
     // PART 2 (:1445-1500), batched.  Warm starts: a vertex y* of the lower image was created by a cut, i.e. by the optimal y of
     // an earlier P1(w'); w(y*) is close to w', so that LP's basis (kept in a tableau slot as long as the pool allows, oldest
     // evicted first, at most 64 generations deep) is the start -- a handful of primal pivots instead of hundreds from the root.
@@ -395,19 +428,46 @@ static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int
             if ((rc = bslv_lpq_get_primal(lp, np, dst.data(), M + n, q, Y.data()))) return done(rc);
             if ((rc = bslv_lpq_get_obj(lp, np, dst.data(), obj.data()))) return done(rc);
             cuts.clear();
-            std::vector<int> cut_src, cut_slot;
+            std::vector<int> cut_src, cut_slot, cut_t;
+            // (u, w) of a confirmed vertex: u = duals of the m rows of A (the reference reads lp_dual_solution_COLS 1..m here,
+            // :1493 -- reduced costs of the first m columns, which is u only by accident of the indices and runs past the
+            // columns when m > n + q; the rows are what the file is documented to hold), w = the weights of its LP
+            auto store_uw = [&](int t, int element) -> int {
+                std::vector<double> uw(m + q);
+                const int sl = dst[t];
+                int r2 = bslv_lpq_get_dual(lp, 1, &sl, 0, m, uw.data());
+                if (r2) return r2;
+                for (int k = 0; k < q; k++) uw[m + k] = W[(size_t)t * q + k];
+                store->uw_by_element[element] = uw;
+                return 0;
+            };
             for (int t = 0; t < np; t++) {
                 const double opt_val = vals[(size_t)pts[t] * q + q - 1];
-                if (opt_val - obj[t] > eps) { cuts.insert(cuts.end(), &Y[(size_t)t * q], &Y[(size_t)t * q] + q); cut_src.push_back(idx[pts[t]]); cut_slot.push_back(dst[t]); }   // :1479-1486
-                else { marks.push_back(idx[pts[t]]); free_slots.push_back(dst[t]); }                                                    // :1488-1497
+                if (opt_val - obj[t] > eps) { cuts.insert(cuts.end(), &Y[(size_t)t * q], &Y[(size_t)t * q] + q); cut_src.push_back(idx[pts[t]]); cut_slot.push_back(dst[t]); cut_t.push_back(t); }   // :1479-1486
+                else {                                                                                                                  // :1488-1497
+                    marks.push_back(idx[pts[t]]);
+                    if (store && (rc = store_uw(t, idx[pts[t]]))) return done(rc);
+                    free_slots.push_back(dst[t]);
+                }
             }
             const int nc = (int)cut_src.size();
             if (nc > 0) {
                 const int f0 = bslv_poly_ndual(poly);                                // facet ids of the new cuts: f0, f0 + 1, ...
                 if ((rc = bslv_poly_add_cuts(poly, nc, cuts.data(), nullptr, rcv.data()))) return done(rc);
                 for (int k = 0; k < nc; k++) {
-                    if (rcv[k]) { marks.push_back(cut_src[k]); free_slots.push_back(cut_slot[k]); }      // nothing was cut off: the vertex stays, processed
-                    else { facet_slot[f0 + k] = cut_slot[k]; young.emplace_back(f0 + k, cut_slot[k]); }
+                    if (rcv[k]) {                                                    // nothing was cut off: the vertex stays, processed
+                        marks.push_back(cut_src[k]);
+                        if (store && (rc = store_uw(cut_t[k], cut_src[k]))) return done(rc);
+                        free_slots.push_back(cut_slot[k]);
+                    } else {
+                        facet_slot[f0 + k] = cut_slot[k]; young.emplace_back(f0 + k, cut_slot[k]);
+                        if (store) {                                                 // x of the new vertex of the upper image (:1484-1485)
+                            std::vector<double> x(n);
+                            const int sl = cut_slot[k];
+                            if ((rc = bslv_lpq_get_primal(lp, 1, &sl, M, n, x.data()))) return done(rc);
+                            store->x_by_facet[f0 + k] = x;
+                        }
+                    }
                 }
             }
         }
@@ -417,9 +477,9 @@ static int dual_benson(const Problem &pb, const Sol &S, int hom, double eps, int
     return done(0);
 }
 
-static int phase2_dual(const Problem &pb, const Sol &S, double eps, int batch, bslv_poly **poly_out, int *status, long *lps, long *steps)
+static int phase2_dual(const Problem &pb, const Sol &S, double eps, int batch, bslv_poly **poly_out, int *status, long *lps, long *steps, DualPreimg *store = nullptr)
 {
-    return dual_benson(pb, S, 0, eps, batch, poly_out, status, lps, steps);
+    return dual_benson(pb, S, 0, eps, batch, poly_out, status, lps, steps, store);
 }
 
 // ---- phase 1, dual algorithm (bslv_algs.c:1248-1371): the dual variant on the homogeneous problem; R from the vertices of
@@ -627,12 +687,75 @@ int bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
     Problem pb{m, n, q, A, Pn.data(), rtype, rlb, rub, ctype, clb, cub};
     int vst = 0;
     bslv_poly *poly = nullptr;
-    if ((rc = phase2_dual(pb, S, eps_benson_phase2, batch, &poly, &vst, &lps, &steps))) return rc;
-    if (vst) { *vlp_status = vst; phase2_failure(info, vst, bounded, lps); return 0; }
+    DualPreimg *store = (flags & BSLV_VLP_PREIMAGES) ? new DualPreimg() : nullptr;
+    if (store) { store->m = m; store->n = n; store->q = q; }
+    if ((rc = phase2_dual(pb, S, eps_benson_phase2, batch, &poly, &vst, &lps, &steps, store))) { delete store; return rc; }
+    if (vst) { delete store; *vlp_status = vst; phase2_failure(info, vst, bounded, lps); return 0; }
+    if (store) {
+        // pre-images of the extreme DIRECTIONS of the upper image (dual slots that are directions; bslv_algs.c:1508-1535): x of
+        // the homogeneous P2 with the bound Z'd on the cone rows and the eta row switched off, one LP per direction.  (The
+        // reference indexes Z with the stride of R there, sol->Z[k*sol->r+j] at :1533 against k*sol->p+j at :1106: right only
+        // when p = r; the stride used here is p.)
+        const int p = S.p, nd = bslv_poly_ndual(poly);
+        std::vector<unsigned char> du(nd), di(nd);
+        std::vector<double> dc((size_t)nd * q);
+        if ((rc = bslv_poly_get_dual(poly, du.data(), di.data(), dc.data()))) { delete store; bslv_poly_destroy(poly); return rc; }
+        bslv_benson *hh = nullptr;
+        if ((rc = bslv_benson_create_ex(&hh, pb.m, pb.n, q, pb.A, pb.P, pb.rtype, pb.rlb, pb.rub, pb.ctype, pb.clb, pb.cub,
+                                        S.Z.data(), p, S.c.data(), nullptr, 1, 0, 1e-7, 4))) { delete store; bslv_poly_destroy(poly); return rc; }
+        bslv_lpq *lp = bslv_benson_lp(hh);
+        int M2, N2, folded;
+        bslv_benson_lp_dims(hh, &M2, &N2, &folded);
+        rc = bslv_lpq_reset_slot(lp, 0);
+        const int zero = 0;
+        std::vector<double> ub(p), x(n);
+        for (int f = 0; f < nd && !rc; f++) {
+            if (!du[f] || !di[f]) continue;
+            for (int j = 0; j < p; j++) { double sdot = 0; for (int k = 0; k < q; k++) sdot += S.Z[(size_t)k * p + j] * dc[(size_t)f * q + k]; ub[j] = sdot; }
+            int st2;
+            if ((rc = solve0(lp, p, ub.data(), &st2))) break;
+            if (st2 != BSLV_LP_OPTIMAL) { set_error("pre-image of a direction: LP status %d (the reference asserts optimality, bslv_algs.c:1537)", st2); rc = BSLV_E_STATE; break; }
+            ++lps;
+            if ((rc = bslv_lpq_get_primal(lp, 1, &zero, M2, n, x.data()))) break;
+            store->x_by_facet[f] = x;
+        }
+        bslv_benson_destroy(hh);
+        if (rc) { delete store; bslv_poly_destroy(poly); return rc; }
+        std::lock_guard<std::mutex> lk(g_dpre_mu);
+        g_dpre[poly] = store;
+    }
     *lower_image_out = poly;
     *vlp_status = 4;
     fill_info(info, S, optdir, lps, steps);
     return 0;
+}
+
+// pre-images kept by bslv_vlp_solve_dual2 with BSLV_VLP_PREIMAGES: 0 + data, or 1 when nothing is stored
+int bslv_dual_preimage_x(const bslv_poly *lower_image, int facet, double *x)
+{
+    std::lock_guard<std::mutex> lk(g_dpre_mu);
+    auto it = g_dpre.find(lower_image);
+    if (it == g_dpre.end() || !x) return 1;
+    auto jt = it->second->x_by_facet.find(facet);
+    if (jt == it->second->x_by_facet.end()) return 1;
+    memcpy(x, jt->second.data(), jt->second.size() * sizeof(double));
+    return 0;
+}
+int bslv_dual_preimage_uw(const bslv_poly *lower_image, int element, double *uw)
+{
+    std::lock_guard<std::mutex> lk(g_dpre_mu);
+    auto it = g_dpre.find(lower_image);
+    if (it == g_dpre.end() || !uw) return 1;
+    auto jt = it->second->uw_by_element.find(element);
+    if (jt == it->second->uw_by_element.end()) return 1;
+    memcpy(uw, jt->second.data(), jt->second.size() * sizeof(double));
+    return 0;
+}
+void bslv_dual_preimages_free(const bslv_poly *lower_image)
+{
+    std::lock_guard<std::mutex> lk(g_dpre_mu);
+    auto it = g_dpre.find(lower_image);
+    if (it != g_dpre.end()) { delete it->second; g_dpre.erase(it); }
 }
 
 void bslv_vlp_info_free(bslv_vlp_info *info)

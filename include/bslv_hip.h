@@ -283,6 +283,13 @@ int  bslv_vlp_solve_dual2(int m, int n, int q, const double *A, const double *P,
                           int optdir, int cone_kind, const double *gen, int n_gen, const double *c_in,
                           int bounded, int flags, double eps_phase0, double eps_phase1, double eps_benson_phase1, double eps_benson_phase2,
                           int batch, bslv_poly **lower_image_out, int *vlp_status, bslv_vlp_info *info /* may be NULL */);
+/* option -s with the dual algorithm (flags & BSLV_VLP_PREIMAGES in bslv_vlp_solve_dual2; phase2_dual with PRE_IMG_ON,
+ * bslv_algs.c:1388-1389, 1431-1432, 1484-1497, 1508-1546): x (n values) of an element of the UPPER image = dual slot `facet` of the
+ * returned polyhedron, (u, w) (m + q values) of a vertex of the LOWER image = its primal element.  0 + data, 1: nothing stored.
+ * bslv_dual_preimages_free before bslv_poly_destroy. */
+int  bslv_dual_preimage_x(const bslv_poly *lower_image, int facet, double *x);
+int  bslv_dual_preimage_uw(const bslv_poly *lower_image, int element, double *uw);
+void bslv_dual_preimages_free(const bslv_poly *lower_image);
 void bslv_vlp_info_free(bslv_vlp_info *info);
 /* cone_vertenum: prim = the non-redundant generators among gen (dim x n_prim), dual = generators of the dual cone
  * (dim x n_dual); malloc'ed, free with bslv_free.  rc_out 1: the cone has no interior (poly__intl_apprx failed). */
@@ -308,6 +315,8 @@ int  bslv_sol_write2(bslv_poly *poly, const char *base, const char *suffix, int 
  * and w by c_dir as the reference stores them (:1068-1070). */
 int  bslv_sol_write_preimages(bslv_benson *eng, const char *base, const char *suffix, int m, int n, int optdir, int c_dir);
 int  bslv_sol_write3(bslv_poly *poly, const char *base, const char *suffix, int swap, int negate_upper, int negate_lower_last, long *counts);
+/* the pre-image files of the dual algorithm: rows in the order of the _img_ files written by bslv_sol_write3(..., swap = 1, ...) */
+int  bslv_sol_write_preimages_dual(bslv_poly *lower_image, const char *base, const char *suffix, int m, int n, int optdir, int c_dir);
 
 #ifdef __cplusplus
 }

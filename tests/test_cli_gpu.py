@@ -127,8 +127,9 @@ def test_cli_ex01_known_answer(tmp_path):
     assert open(base + "_c.sol").read().split() == ["1", "1"]
 
 
+@pytest.mark.parametrize("alg", ["primal", "dual"])
 @pytest.mark.parametrize("m,n,q,seed,bounded", [(30, 15, 3, 5, True), (20, 10, 2, 3, False)])
-def test_cli_solution_files(tmp_path, m, n, q, seed, bounded):
+def test_cli_solution_files(tmp_path, m, n, q, seed, bounded, alg):
     """Option -s (opt->solution == PRE_IMG_ON): <name>_pre_img_p.sol holds an x for every element of the upper image (its
     image P x is the vertex), <name>_pre_img_d.sol a dual solution (u, w) for every vertex of the lower image: u >= 0 on the
     cover rows, A'u <= P'w (the columns are x >= 0), b'u = y*_q, w = (y*_1 .. y*_{q-1}, 1 - sum)."""
@@ -136,7 +137,9 @@ def test_cli_solution_files(tmp_path, m, n, q, seed, bounded):
     path = os.path.join(tmp_path, "prob.vlp")
     synth.write_vlp(prob, path)
     base = os.path.join(tmp_path, "hip")
-    r = subprocess.run([CLI, path, "-s", "-m", "1", "-B", "32", "-o", base] + (["-b"] if bounded else []), capture_output=True, text=True, timeout=300)
+    # (-a dual: phase2_dual with PRE_IMG_ON, bslv_algs.c:1388-1389, 1484-1497, 1508-1546 -- x comes with every cut of the lower
+    # image, (u, w) with every confirmed vertex of it; same files, same meaning)
+    r = subprocess.run([CLI, path, "-s", "-m", "1", "-B", "32", "-a", alg, "-o", base] + (["-b"] if bounded else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     img = np.array([[float(x) for x in l.split()] for l in open(base + "_img_p.sol").read().strip().splitlines()])
     pre = np.array([[float(x) for x in l.split()] for l in open(base + "_pre_img_p.sol").read().strip().splitlines()])
