@@ -224,22 +224,34 @@ __device__ __forceinline__ unsigned long long spread32(unsigned x)
     v = (v | (v << 1)) & 0x5555555555555555ull;
     return v;
 }
-template <int D, bool TOUCH>
-__device__ __forceinline__ void classify_batch_body(const PolyView &P, const double *__restrict__ hps, int B, int nv,
-                                                    unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
-                                                    int *__restrict__ tc, int *__restrict__ t1, const int i)
+// acc = 2 acc + (s > t), t wave-uniform: the compare leaves its mask in VCC and ONE add-with-carry shifts the bit in (the compiler
+// builds the word from v_cndmask + v_or3 + shifts: two vector instructions per bit instead of one)
+__device__ __forceinline__ void shift_in_gt(unsigned &acc, double s, double t)
+{
+    asm("v_cmp_lt_f64 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(s), "s"(t) : "vcc");
+}
+// one element per lane: coordinates and flag byte in registers (classify_load), then its classes against the B halfspaces
+template <int D>
+__device__ __forceinline__ void classify_load(const PolyView &P, int nv, int i, double (&x)[D > 0 ? D : MAXD], unsigned char &fl)
 {
     const int d = D > 0 ? D : P.d;
-    bool live = false, ideal = false;
-    double x[D > 0 ? D : MAXD];
+    fl = 0;
 #pragma unroll
     for (int k = 0; k < (D > 0 ? D : MAXD); k++) x[k] = 0.0;
     if (i < nv) {
-        unsigned char fl = P.flag[i];
-        live = fl & F_USED; ideal = fl & F_IDEAL;
+        fl = P.flag[i];
 #pragma unroll
         for (int k = 0; k < (D > 0 ? D : MAXD); k++) if (k < d) x[k] = P.X[(size_t)k * P.cap + i];
     }
+}
+template <int D, bool TOUCH>
+__device__ __forceinline__ void classify_elem(const PolyView &P, const double *__restrict__ hps, int B, int nv,
+                                              unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
+                                              int *__restrict__ tc, int *__restrict__ t1, const int i,
+                                              const double (&x)[D > 0 ? D : MAXD], const unsigned char fl)
+{
+    const int d = D > 0 ? D : P.d;
+    const bool live = fl & F_USED, ideal = fl & F_IDEAL;
     const bool wave_has_ideal = __ballot(ideal) != 0ull;      // directions are rare: scalar thresholds on the fast path
     const int nw = (B + 31) / 32;
     int touch = 0, first = -1;
@@ -256,8 +268,8 @@ __device__ __forceinline__ void classify_batch_body(const PolyView &P, const dou
 #pragma unroll
                 for (int k = 0; k < (D > 0 ? D : MAXD); k++) if (k < d) s = fma(h[k], x[k], s);
                 const double hi = h[d + 1], lo = h[d + 2];                    // alpha +- EPS, precomputed on the host
-                plus |= (unsigned)(s > hi) << bb;
-                notminus |= (unsigned)(s > lo) << bb;
+                shift_in_gt(plus, s, hi);
+                shift_in_gt(notminus, s, lo);
             }
         } else if (!wave_has_ideal) {
             for (int bb = 0; bb < bend; bb++) {
@@ -266,8 +278,8 @@ __device__ __forceinline__ void classify_batch_body(const PolyView &P, const dou
 #pragma unroll
                 for (int k = 0; k < (D > 0 ? D : MAXD); k++) if (k < d) s = fma(h[k], x[k], s);
                 const double hi = h[d + 1], lo = h[d + 2];
-                plus |= (unsigned)(s > hi) << bb;
-                notminus |= (unsigned)(s > lo) << bb;
+                shift_in_gt(plus, s, hi);
+                shift_in_gt(notminus, s, lo);
             }
         } else {
             for (int bb = 0; bb < bend; bb++) {
@@ -276,10 +288,12 @@ __device__ __forceinline__ void classify_batch_body(const PolyView &P, const dou
 #pragma unroll
                 for (int k = 0; k < (D > 0 ? D : MAXD); k++) if (k < d) s = fma(h[k], x[k], s);
                 const double a = ideal ? 0.0 : h[d];
-                plus |= (unsigned)(s > a + POLY_EPS) << bb;
-                notminus |= (unsigned)(s > a - POLY_EPS) << bb;
+                plus = plus + plus + (unsigned)(s > a + POLY_EPS);
+                notminus = notminus + notminus + (unsigned)(s > a - POLY_EPS);
             }
         }
+        // (the bits were shifted in from the right -- one add-with-carry per compare: halfspace 0 sits at bit bend - 1)
+        plus = __brev(plus) >> (32 - bend); notminus = __brev(notminus) >> (32 - bend);
         // class = 1 MINUS (01), 2 ZERO (10), 3 PLUS (11): low bit = plus | !notminus, high bit = notminus
         unsigned lowb = (plus | ~notminus) & valid, highb = notminus & valid;
         unsigned minusbits = ~notminus & valid;
@@ -300,17 +314,263 @@ __device__ __forceinline__ void classify_batch_body(const PolyView &P, const dou
     if (TOUCH && i < nv) { tc[i] = touch; t1[i] = first; }
 }
 template <int D, bool TOUCH>
+__device__ __forceinline__ void classify_batch_body(const PolyView &P, const double *__restrict__ hps, int B, int nv,
+                                                    unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
+                                                    int *__restrict__ tc, int *__restrict__ t1, const int i)
+{
+    double x[D > 0 ? D : MAXD]; unsigned char fl;
+    classify_load<D>(P, nv, i, x, fl);
+    classify_elem<D, TOUCH>(P, hps, B, nv, out, anyminus, tc, t1, i, x, fl);
+}
+// Grid-stride over the elements with the next element's coordinates requested before the current one is classified.  Measured
+// (scripts/probe/k1_small_b.py, q = 5, 8 M elements): a grid capped at 4..16 workgroups per CU is 3-15 % SLOWER at B = 2..32 than
+// one workgroup per 256 elements, so the launch is not capped and the loop runs once; it stays for nv beyond one grid.  Unrolling
+// the partial-word loop by 2, 4 or 8 changes nothing (same box, +-2 %).
+constexpr int K1_MAX_BLOCKS = 1 << 22;
+template <int D, bool TOUCH>
 __global__ __launch_bounds__(PB) void k_classify_batch_t(PolyView P, const double *__restrict__ hps, int B, int nv,
                                                          unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
                                                          int *__restrict__ tc, int *__restrict__ t1)
 {
-    classify_batch_body<D, TOUCH>(P, hps, B, nv, out, anyminus, tc, t1, (int)(blockIdx.x * PB + threadIdx.x));
+    const int stride = (int)gridDim.x * PB;
+    int i = (int)(blockIdx.x * PB + threadIdx.x);
+    if (i - (int)(threadIdx.x & 63) >= nv) return;                     // (wave-uniform)
+    double x[D > 0 ? D : MAXD]; unsigned char fl;
+    classify_load<D>(P, nv, i, x, fl);
+    for (;;) {
+        const int inext = i + stride;
+        const bool more = inext - (int)(threadIdx.x & 63) < nv;       // (wave-uniform; no overflow: nv + stride < 2^31 by the launch)
+        double xn[D > 0 ? D : MAXD]; unsigned char fln = 0;
+        if (more) classify_load<D>(P, nv, inext, xn, fln);
+        classify_elem<D, TOUCH>(P, hps, B, nv, out, anyminus, tc, t1, i, x, fl);
+        if (!more) break;
+        i = inext; fl = fln;
+        for (int k = 0; k < (D > 0 ? D : MAXD); k++) x[k] = xn[k];
+    }
 }
 
+// ---- K1 on the matrix pipe (round 2) -------------------------------------------------------------------------------------
+// The scalar kernel above is VALU-bound from B ~ 16 on: per (element, halfspace) 5 fp64 FMAs, 2 fp64 compares and ~4 integer
+// operations for the bit packing share the vector ALU (24 TFLOP/s useful, 30-36 % of the HBM peak at B = 16..32).  Here the dot
+// products go to v_mfma_f64_16x16x4 -- one tile = 16 elements x 16 halfspaces, K = the coordinates in steps of 4 (zero padded) --
+// and the compares come out of the vector ALU as WAVE MASKS (v_cmp writes an SGPR pair: the "ballot" is free), so no lane packs
+// bits.  (fp64 matrix peak = fp64 vector peak on gfx950: the gain is the vector ALU freed of the FMAs, not a higher peak.)
+//   A[i][k] = X[k][element i]   lane l holds A[l & 15][l >> 4]              (one f64 per lane and K step)
+//   B[k][j] = h_j[k]            lane l holds B[l >> 4][l & 15]
+//   D[i][j] = h_j . x_i         lane l holds rows (l >> 4) + 4 r, r = 0..3, of column l & 15
+// A wave owns 64 elements = 4 tiles and keeps their A operands in registers; per 16 halfspaces it runs 4 independent MFMA chains.
+// Mask (t, r) of tile t, result register r: bits 16 g .. 16 g + 15 are the 16 halfspace bits of element 16 t + 4 r + g.  Read as a
+// string of 16-bit fields in the order (t, r, g) the field number IS the element's lane: the 32 mask dwords are dropped into lanes
+// 0..31 of one register (v_writelane), lane L fetches dword L >> 1 (one ds_bpermute) and keeps half L & 1.
+// Same result bit for bit as the scalar fma chain: the K steps of one MFMA are accumulated in ascending k with one rounding per
+// step, chained MFMAs continue the chain, the padding adds fma(0, 0, s) = s (bslv_k1_mfma_selftest; and the class words against
+// the scalar kernel on random data and inside the +-1e-9 bands: tests/test_poly_gpu.py).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+// The 8 wave masks of one tile (4 result registers x {> alpha + EPS, > alpha - EPS}) and their hand-off into lanes 8 t .. 8 t + 7
+// of mp / mn.  Written as two blocks of assembly so that the ORDER is fixed: v_writelane_b32 fetches its scalar source ahead of the
+// vector pipeline -- issued right behind the v_cmp_f64 that produces the mask it picked up the register's previous content now and
+// then (seen as lost PLUS bits against the scalar kernel).  Here every mask is at least 8 vector instructions old when it is read.
+template <int T0>
+__device__ __forceinline__ void tile_masks(const d4_t &acc, double hi, double lo, int &mp, int &mn)
+{
+    unsigned long long p0, p1, p2, p3, n0, n1, n2, n3;
+    asm volatile("v_cmp_gt_f64 %0, %8, %12\n\tv_cmp_gt_f64 %1, %9, %12\n\tv_cmp_gt_f64 %2, %10, %12\n\tv_cmp_gt_f64 %3, %11, %12\n\t"
+                 "v_cmp_gt_f64 %4, %8, %13\n\tv_cmp_gt_f64 %5, %9, %13\n\tv_cmp_gt_f64 %6, %10, %13\n\tv_cmp_gt_f64 %7, %11, %13"
+                 : "=&s"(p0), "=&s"(p1), "=&s"(p2), "=&s"(p3), "=&s"(n0), "=&s"(n1), "=&s"(n2), "=&s"(n3)
+                 : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(hi), "v"(lo));
+    asm volatile("v_writelane_b32 %0, %2, %18\n\tv_writelane_b32 %0, %3, %19\n\tv_writelane_b32 %0, %4, %20\n\tv_writelane_b32 %0, %5, %21\n\t"
+                 "v_writelane_b32 %0, %6, %22\n\tv_writelane_b32 %0, %7, %23\n\tv_writelane_b32 %0, %8, %24\n\tv_writelane_b32 %0, %9, %25\n\t"
+                 "v_writelane_b32 %1, %10, %18\n\tv_writelane_b32 %1, %11, %19\n\tv_writelane_b32 %1, %12, %20\n\tv_writelane_b32 %1, %13, %21\n\t"
+                 "v_writelane_b32 %1, %14, %22\n\tv_writelane_b32 %1, %15, %23\n\tv_writelane_b32 %1, %16, %24\n\tv_writelane_b32 %1, %17, %25"
+                 : "+v"(mp), "+v"(mn)
+                 : "s"((unsigned)p0), "s"((unsigned)(p0 >> 32)), "s"((unsigned)p1), "s"((unsigned)(p1 >> 32)),
+                   "s"((unsigned)p2), "s"((unsigned)(p2 >> 32)), "s"((unsigned)p3), "s"((unsigned)(p3 >> 32)),
+                   "s"((unsigned)n0), "s"((unsigned)(n0 >> 32)), "s"((unsigned)n1), "s"((unsigned)(n1 >> 32)),
+                   "s"((unsigned)n2), "s"((unsigned)(n2 >> 32)), "s"((unsigned)n3), "s"((unsigned)(n3 >> 32)),
+                   "n"(8 * T0), "n"(8 * T0 + 1), "n"(8 * T0 + 2), "n"(8 * T0 + 3), "n"(8 * T0 + 4), "n"(8 * T0 + 5), "n"(8 * T0 + 6), "n"(8 * T0 + 7));
+}
+template <int I, int N> struct StaticFor {
+    template <class F> static __device__ __forceinline__ void run(F &&f) { f(std::integral_constant<int, I>{}); StaticFor<I + 1, N>::run(f); }
+};
+template <int N> struct StaticFor<N, N> { template <class F> static __device__ __forceinline__ void run(F &&) {} };
+template <int D, bool TOUCH>
+__global__ __launch_bounds__(PB) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_classify_batch_mfma(PolyView P, const double *__restrict__ hps, int B, int nv,
+                                                            unsigned long long *__restrict__ out, unsigned *__restrict__ anyminus,
+                                                            int *__restrict__ tc, int *__restrict__ t1)
+{
+    constexpr int KS = (D + 3) / 4;                                   // K steps
+    constexpr int T = 4;                                              // tiles per wave
+    const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
+    const int base = (int)((blockIdx.x * PB + threadIdx.x) >> 6) * 64;
+    if (base >= nv) return;                                           // (wave-uniform)
+    double a[T][KS];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int k = 4 * ks + kq, e = base + 16 * t + col;
+            a[t][ks] = (e < nv && k < D) ? P.X[(size_t)k * P.cap + e] : 0.0;
+        }
+    const int e = base + lane;                                        // the element this lane writes
+    const bool mine = e < nv;
+    const unsigned char fl = mine ? P.flag[e] : 0;
+    const bool live = fl & F_USED;
+    // directions are measured against 0 (bslv_poly.c:126), i.e. with thresholds per ROW of a tile: a wave that holds one (rare)
+    // takes the scalar path for its 64 elements
+    if (__ballot(fl & F_IDEAL)) { classify_batch_body<D, TOUCH>(P, hps, B, nv, out, anyminus, tc, t1, e); return; }
+    const int nw = (B + 31) / 32, nh = (B + 15) / 16;
+    // operand B and the thresholds of the first 16 halfspaces (each half is fetched while the previous one is multiplied)
+    double bq[KS], hi, lo;
+    {
+        const bool hv = col < B;
+        const double *h = hps + (size_t)(hv ? col : 0) * (D + 3);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) { const int k = 4 * ks + kq; bq[ks] = (hv && k < D) ? h[k] : 0.0; }
+        hi = hv ? h[D + 1] : INFINITY; lo = hv ? h[D + 2] : INFINITY; // alpha +- EPS (an absent halfspace: no bit)
+    }
+    int touch = 0, first = -1;
+    for (int w = 0; w < nw; w++) {
+        unsigned plus32 = 0, nm32 = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int hx = 2 * w + half;
+            double bc[KS]; const double chi = hi, clo = lo;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) bc[ks] = bq[ks];
+            if (hx + 1 < nh) {                                        // prefetch
+                const int hs = (hx + 1) * 16 + col;
+                const bool hv = hs < B;
+                const double *h = hps + (size_t)(hv ? hs : 0) * (D + 3);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) { const int k = 4 * ks + kq; bq[ks] = (hv && k < D) ? h[k] : 0.0; }
+                hi = hv ? h[D + 1] : INFINITY; lo = hv ? h[D + 2] : INFINITY;
+            }
+            if (hx >= nh) break;                                      // (B <= 16 (mod 32): the second half is empty)
+            d4_t acc[T];
+#pragma unroll
+            for (int t = 0; t < T; t++) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+                for (int t = 0; t < T; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][ks], bc[ks], acc[t], 0, 0, 0);
+            int mp = 0, mn = 0;                                       // lanes 0..31: the mask dwords in the order (t, r, low | high)
+            // the compares below are assembly, which the compiler's hazard recogniser does not look into: all MFMAs first, then the
+            // wait states a vector read of a 16-pass MFMA result needs (19), once
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+            StaticFor<0, T>::run([&](auto ic) { tile_masks<decltype(ic)::value>(acc[decltype(ic)::value], chi, clo, mp, mn); });
+            const unsigned fp = (unsigned)__builtin_amdgcn_ds_bpermute((lane >> 1) << 2, mp), fn = (unsigned)__builtin_amdgcn_ds_bpermute((lane >> 1) << 2, mn);
+            plus32 |= ((fp >> (16 * (lane & 1))) & 0xFFFFu) << (16 * half);
+            nm32 |= ((fn >> (16 * (lane & 1))) & 0xFFFFu) << (16 * half);
+        }
+        const int bend = min(32, B - w * 32);
+        const unsigned valid = bend == 32 ? 0xFFFFFFFFu : ((1u << bend) - 1u);
+        unsigned lowb = (plus32 | ~nm32) & valid, highb = nm32 & valid, minusbits = ~nm32 & valid;
+        if (!live) { lowb = 0; highb = 0; minusbits = 0; }
+        if (mine) out[(size_t)w * P.cap + e] = spread32(lowb) | (spread32(highb) << 1);
+        if (TOUCH) {
+            const unsigned nonplus = live ? (~plus32 & valid) : 0u;
+            if (nonplus) { if (touch == 0) first = w * 32 + (__ffs((int)nonplus) - 1); touch += __popc(nonplus); }
+        }
+        if (anyminus) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) minusbits |= __shfl_xor(minusbits, o, WAVE);
+            if (lane == 0 && (minusbits & ~__hip_atomic_load(&anyminus[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicOr(&anyminus[w], minusbits);
+        }
+    }
+    if (TOUCH && mine) { tc[e] = touch; t1[e] = first; }
+}
+
+// self-test of the claim above: the dot products of random 16 x 16 tiles by chained MFMAs against the scalar fma chain, bit for bit
+template <int D>
+__global__ void k_k1_mfma_selftest(const double *__restrict__ X /* D x 16 per tile */, const double *__restrict__ H /* 16 x D per tile */, int ntiles, unsigned long long *mismatch)
+{
+    constexpr int KS = (D + 3) / 4;
+    const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
+    const int tile = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (tile >= ntiles) return;
+    const double *x = X + (size_t)tile * D * 16, *h = H + (size_t)tile * 16 * D;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const int k = 4 * ks + kq;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < D ? x[k * 16 + col] : 0.0, k < D ? h[col * D + k] : 0.0, acc, 0, 0, 0);
+    }
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = kq + 4 * r;                       // element row of this result, column = halfspace col
+        double sref = 0.0;
+        for (int k = 0; k < D; k++) sref = fma(h[col * D + k], x[k * 16 + i], sref);
+        bad += __double_as_longlong(sref) != __double_as_longlong(acc[r]);
+    }
+    if (bad) atomicAdd(mismatch, (unsigned long long)bad);
+}
+
+// Which of the two runs: the scalar kernel.  Measured (profiles/r02_f64_pipes.json, scripts/probe/f64_pipes.hip): on gfx950 a wave's
+// v_fma_f64 / v_cmp_f64 make 6-9 % of their stand-alone progress while another wave of the same SIMD issues f64 MFMAs back to back --
+// the f64 MFMA occupies the SIMD's fp64 datapath instead of running beside it, so the dot products cost the same fp64 cycles either
+// way, K padded from 5 to 8 costs 60 % more of them, and the compares + mask hand-off come on top (21.7 against 23.2 TFLOP/s useful
+// at q = 5, B = 512).  BSLV_K1_MFMA=1 or bslv_poly_debug_set key 9 select the matrix kernel (kept: bit-identical, tested).
+static bool g_k1_mfma = getenv("BSLV_K1_MFMA") != nullptr;
 static void launch_classify_batch(hipStream_t s, PolyView P, const double *hps, int B, int nv, unsigned long long *out, unsigned *anyminus,
                                   int *tc, int *t1)
 {
-    dim3 g((nv + PB - 1) / PB), b(PB);
+    if (g_k1_mfma && B >= 16 && P.d >= 2 && P.d <= 10) {
+        dim3 g((unsigned)((nv + PB - 1) / PB)), b(PB);                    // 64 elements per wave
+        static const bool check = getenv("BSLV_K1_CHECK") != nullptr;    // DEBUG: the scalar kernel beside it, outputs compared on the host
+        const int nw = (B + 31) / 32;
+        unsigned long long *out2 = nullptr; unsigned *any2 = nullptr; int *tt2 = nullptr;
+        if (check) {
+            (void)hipMalloc(&out2, (size_t)nw * P.cap * 8); (void)hipMalloc(&any2, nw * 4); (void)hipMalloc(&tt2, (size_t)2 * (nv + 1) * 4);
+            if (anyminus) (void)hipMemcpyAsync(any2, anyminus, nw * 4, hipMemcpyDeviceToDevice, s);
+        }
+        switch (P.d) {
+#define CASE(D) case D: if (tc) hipLaunchKernelGGL((k_classify_batch_mfma<D, true>), g, b, 0, s, P, hps, B, nv, out, anyminus, tc, t1); \
+                       else hipLaunchKernelGGL((k_classify_batch_mfma<D, false>), g, b, 0, s, P, hps, B, nv, out, anyminus, tc, t1); break;
+            CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+        }
+        if (check) {
+            g_k1_mfma = false;
+            launch_classify_batch(s, P, hps, B, nv, out2, anyminus ? any2 : nullptr, tc ? tt2 : nullptr, tc ? tt2 + nv : nullptr);
+            g_k1_mfma = true;
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> wa((size_t)nw * P.cap), wb((size_t)nw * P.cap);
+            std::vector<unsigned> aa(nw), ab(nw); std::vector<int> ta(2 * (size_t)nv), tb(2 * (size_t)nv);
+            (void)hipMemcpy(wa.data(), out, wa.size() * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(wb.data(), out2, wb.size() * 8, hipMemcpyDeviceToHost);
+            if (anyminus) { (void)hipMemcpy(aa.data(), anyminus, nw * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(ab.data(), any2, nw * 4, hipMemcpyDeviceToHost); }
+            if (tc) { (void)hipMemcpy(ta.data(), tc, (size_t)nv * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(ta.data() + nv, t1, (size_t)nv * 4, hipMemcpyDeviceToHost);
+                      (void)hipMemcpy(tb.data(), tt2, (size_t)2 * nv * 4, hipMemcpyDeviceToHost); }
+            long bw = 0, bt = 0, ba = 0; int fw = -1, fi = -1;
+            for (int w = 0; w < nw; w++) for (int i = 0; i < nv; i++) if (wa[(size_t)w * P.cap + i] != wb[(size_t)w * P.cap + i]) { if (!bw) { fw = w; fi = i; } bw++; }
+            if (tc) for (size_t i = 0; i < 2 * (size_t)nv; i++) bt += ta[i] != tb[i];
+            if (anyminus) for (int w = 0; w < nw; w++) ba += aa[w] != ab[w];
+            fprintf(stderr, "K1 check: d %d B %d nv %d cap %d touch %d: words differ %ld (first w %d i %d: %016llx vs %016llx), tc/t1 differ %ld, anyminus differ %ld\n",
+                    P.d, B, nv, P.cap, tc != nullptr, bw, fw, fi, fw >= 0 ? wa[(size_t)fw * P.cap + fi] : 0ull, fw >= 0 ? wb[(size_t)fw * P.cap + fi] : 0ull, bt, ba);
+            if (bw) {
+                std::vector<unsigned char> fl(nv); (void)hipMemcpy(fl.data(), P.flag, nv, hipMemcpyDeviceToHost);
+                std::vector<double> hh((size_t)B * (P.d + 3)); (void)hipMemcpy(hh.data(), hps, hh.size() * 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, "  flags:");
+                for (int i = 0; i < nv && i < 64; i++) fprintf(stderr, " %d:%02x", i, fl[i]);
+                fprintf(stderr, "\n  differing elements:");
+                int shown = 0;
+                for (int i = 0; i < nv && shown < 12; i++) {
+                    bool df = false;
+                    for (int w = 0; w < nw; w++) df |= wa[(size_t)w * P.cap + i] != wb[(size_t)w * P.cap + i];
+                    if (!df) continue;
+                    shown++;
+                    double x[MAXD]; for (int k = 0; k < P.d; k++) (void)hipMemcpy(&x[k], P.X + (size_t)k * P.cap + i, 8, hipMemcpyDeviceToHost);
+                    double s0 = 0; for (int k = 0; k < P.d; k++) s0 = fma(hh[k], x[k], s0);
+                    fprintf(stderr, " [%d fl %02x w0 %016llx vs %016llx s(h0) %.3e alpha0 %.3e]", i, fl[i], wa[i], wb[i], s0, hh[P.d]);
+                }
+                fprintf(stderr, "\n");
+            }
+            (void)hipFree(out2); (void)hipFree(any2); (void)hipFree(tt2);
+        }
+        return;
+    }
+    dim3 g(std::min((nv + PB - 1) / PB, K1_MAX_BLOCKS)), b(PB);
     switch (P.d) {
 #define CASE(D) case D: if (tc) hipLaunchKernelGGL((k_classify_batch_t<D, true>), g, b, 0, s, P, hps, B, nv, out, anyminus, tc, t1); \
                        else hipLaunchKernelGGL((k_classify_batch_t<D, false>), g, b, 0, s, P, hps, B, nv, out, anyminus, tc, t1); break;
@@ -3197,6 +3457,32 @@ int bslv_poly_classify_batch(bslv_poly *h, int B, const double *hps, unsigned lo
     return 0;
 }
 
+// TEST: the same kernel in the form the chunked cut application launches it (with touch counts): tc_out[i] = halfspaces of
+// the batch that element i is not strictly inside, t1_out[i] = the first of them (-1: none); nv ints each
+int bslv_poly_classify_batch_touch(bslv_poly *h, int B, const double *hps, unsigned long long *words_out, int *tc_out, int *t1_out)
+{
+    if (!h || B < 1 || B > 4096 || !hps || !h->initialised || !tc_out || !t1_out) { set_error("bslv_poly_classify_batch_touch: bad argument"); return BSLV_E_ARG; }
+    const int nv = h->nv;
+    int rc;
+    if ((rc = upload_hps(h, hps, B))) return rc;
+    if (B > h->anycap) { if ((rc = grow(&h->anyminus, 0, (size_t)B, h->stream))) return rc; h->anycap = B; }
+    size_t need = (size_t)((B + 31) / 32) * h->P.cap;
+    if (need > h->clswcap) { if ((rc = grow(&h->clsw, 0, need, h->stream))) return rc; h->clswcap = need; }
+    int *tt = nullptr;
+    HIP_TRY(hipMalloc(&tt, (size_t)2 * std::max(nv, 1) * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->anyminus, 0, ((B + 31) / 32) * sizeof(unsigned), h->stream));
+    launch_classify_batch(h->stream, h->P, h->hps_d, B, nv, h->clsw, h->anyminus, tt, tt + nv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(tc_out, tt, (size_t)nv * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t1_out, tt + nv, (size_t)nv * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(tt);
+    if (words_out)
+        for (int w = 0; w < (B + 31) / 32; w++)
+            HIP_TRY(hipMemcpy(words_out + (size_t)w * nv, h->clsw + (size_t)w * h->P.cap, (size_t)nv * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // all unprocessed elements (used && !sltn) in ascending slot order: the set poly__get_vrtx
 // iterates (bslv_poly.c:214-216).  *count = how many exist; at most max_out are written.
 int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
@@ -3293,6 +3579,7 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 4: h->fm_min = (int)std::max(2L, value); return 0;
     case 6: h->rounds2_enabled = value != 0; return 0;                  /* device-selected rounds of independent cuts inside a hot chunk */
     case 7: h->chunk_cuts = (int)std::min(4096L, std::max(32L, value)); return 0;    /* cuts classified and applied together */
+    case 9: g_k1_mfma = value != 0; return 0;                            /* incidence kernel K1 on the matrix pipe from 16 halfspaces on (1) or the scalar kernel (0, default); process-wide */
     case 8: h->r2_min_cuts = (int)std::max(-1L, value); return 0;        /* rounds go on while they average at least this many cuts (0: until every round holds one cut, -1: always) */
     case 5: h->member_lists = value != 0; return 0;                     /* edges of large facets confirmed through member lists (1) or against all elements (0) */           /* facets from this size on confirm edges through the facet-major member lists (4096) */
     default: return BSLV_E_ARG;
@@ -3305,6 +3592,34 @@ int bslv_poly_path_stats(const bslv_poly *h, long out[6])
     return 0;
 }
 long bslv_poly_conflict_pairs(const bslv_poly *h) { return h ? h->conf_pairs : 0; }
+// TEST: ntiles random 16 x 16 tiles of dot products of length dim, chained v_mfma_f64_16x16x4 against the scalar fma chain;
+// *mismatches = results that differ in any bit (0 expected: the MFMA accumulates its K steps in ascending order, one rounding each)
+int bslv_k1_mfma_selftest(int dim, int ntiles, unsigned long long seed, long *mismatches)
+{
+    if (dim < 2 || dim > 10 || ntiles < 1 || !mismatches) return BSLV_E_ARG;
+    std::vector<double> X((size_t)ntiles * dim * 16), H((size_t)ntiles * 16 * dim);
+    unsigned long long z = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { z += 0x9E3779B97F4A7C15ull; unsigned long long t = z; t = (t ^ (t >> 30)) * 0xBF58476D1CE4E5B9ull; t = (t ^ (t >> 27)) * 0x94D049BB133111EBull; t ^= t >> 31;
+                       return ((double)(t >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0) * (1.0 + (double)(t & 7)); };
+    for (double &v : X) v = rnd();
+    for (double &v : H) v = rnd();
+    double *Xd = nullptr, *Hd = nullptr; unsigned long long *md = nullptr;
+    HIP_TRY(hipMalloc(&Xd, X.size() * 8)); HIP_TRY(hipMalloc(&Hd, H.size() * 8)); HIP_TRY(hipMalloc(&md, 8));
+    HIP_TRY(hipMemcpy(Xd, X.data(), X.size() * 8, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(Hd, H.data(), H.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(md, 0, 8));
+    const dim3 g((unsigned)(((size_t)ntiles * 64 + 255) / 256)), b(256);
+    switch (dim) {
+#define CASE(D) case D: hipLaunchKernelGGL(k_k1_mfma_selftest<D>, g, b, 0, 0, (const double *)Xd, (const double *)Hd, ntiles, md); break;
+        CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpy(&m, md, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(Xd); (void)hipFree(Hd); (void)hipFree(md);
+    *mismatches = (long)m;
+    return 0;
+}
 // device-selected rounds inside hot chunks: out[0] rounds, [1] cuts applied in them, [2] chunks, [3] prunes that went through the
 // multi-kernel path, [4] rounds taken back for want of capacity
 int bslv_poly_rounds2_stats(const bslv_poly *h, long out[5])

@@ -31,6 +31,8 @@ def _bind(lib):
     lib.bslv_poly_mark.argtypes = [vp, i, vp]
     lib.bslv_poly_dual_adjacency.argtypes = [vp]
     lib.bslv_poly_classify_batch.argtypes = [vp, i, vp, vp, vp, i, vp]
+    if hasattr(lib, "bslv_poly_classify_batch_touch"):                  # (TEST entry; absent from older builds used in A/B probes)
+        lib.bslv_poly_classify_batch_touch.argtypes = [vp, i, vp, vp, vp, vp]
     lib.bslv_poly_bench_fill.argtypes = [vp, i, ctypes.c_ulonglong]
     for n in ("dim", "nprimal", "ndual"):
         getattr(lib, "bslv_poly_" + n).argtypes = [vp]
@@ -146,6 +148,16 @@ class PolyEngine:
         check(self.lib.bslv_poly_classify_batch(self.h, B, hps.ctypes.data, None if words is None else words.ctypes.data,
                                                 anym.ctypes.data, repeats, ctypes.byref(ms)))
         return words, anym, ms.value
+
+    def classify_batch_touch(self, hps):
+        """TEST: K1 as the chunked cut application launches it -> (words, touch counts, first touched halfspace)"""
+        hps = np.ascontiguousarray(hps, np.float64).reshape(-1, self.d + 1)
+        B = len(hps)
+        nv = self.lib.bslv_poly_nprimal(self.h)
+        words = np.zeros(((B + 31) // 32, nv), np.uint64)
+        tc, t1 = np.zeros(nv, np.int32), np.zeros(nv, np.int32)
+        check(self.lib.bslv_poly_classify_batch_touch(self.h, B, hps.ctypes.data, words.ctypes.data, tc.ctypes.data, t1.ctypes.data))
+        return words, tc, t1
 
     def bench_fill(self, nv, seed=1):
         check(self.lib.bslv_poly_bench_fill(self.h, int(nv), int(seed)))

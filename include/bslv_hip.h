@@ -150,6 +150,14 @@ int  bslv_poly_dual_adjacency(bslv_poly *h);                  /* poly__update_ad
  * words_out: ceil(B/32) x nprimal 64-bit words, 2 bits per class (0 dead 1 MINUS 2 ZERO 3 PLUS) */
 int  bslv_poly_classify_batch(bslv_poly *h, int B, const double *hps, unsigned long long *words_out,
                               int *anyminus_out, int repeats, float *ms_out);
+/* TEST: the incidence kernel as the chunked cut application launches it: tc_out[i] = halfspaces element i is not strictly
+ * inside, t1_out[i] = the first of them or -1 (nv ints each); words_out as bslv_poly_classify_batch (may be NULL) */
+int  bslv_poly_classify_batch_touch(bslv_poly *h, int B, const double *hps, unsigned long long *words_out, int *tc_out, int *t1_out);
+/* TEST: the incidence kernel has a variant that runs its dot products on v_mfma_f64_16x16x4 (from 16 halfspaces on; selected by
+ * bslv_poly_debug_set key 9 = 1 or BSLV_K1_MFMA=1; the scalar kernel is the default because it is faster on gfx950):
+ * ntiles random tiles, chained MFMAs against the scalar fma chain, *mismatches = results that differ in any bit (0: same order
+ * of accumulation, one rounding per step) */
+int  bslv_k1_mfma_selftest(int dim, int ntiles, unsigned long long seed, long *mismatches);
 /* MEASUREMENT ONLY: replace the polyhedron by nv synthetic live points (for timing the incidence kernel) */
 int  bslv_poly_bench_fill(bslv_poly *h, int nv, unsigned long long seed);
 /* counts and slot-indexed dumps (poly__vrtx2file / adj2file / inc2file write these, :341-414) */

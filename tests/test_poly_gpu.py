@@ -244,3 +244,76 @@ def test_full_size_properties_q5_N1000():
     assert np.array_equal(d2["pu"], np.concatenate([d["pu"]])) and np.array_equal(d2["E"], d["E"])
     assert int(pts.sum()) == 27222       # same input as the oracle/reference comparison run (seed 5)
     G.close()
+
+
+def test_k1_on_the_matrix_pipe_is_bit_identical_to_the_scalar_kernel():
+    """K1 (the batched incidence kernel) has a variant that computes its dot products with v_mfma_f64_16x16x4 (debug key 9; not the
+    default: DESIGN.md 4).  (1) The raw results of chained MFMAs equal the scalar fma chain in every bit (same order of
+    accumulation): 20 000 random tiles per dimension.  (2) The class words, touch counts, first touched halfspace and 'some
+    element violates' flags of the two kernels are identical on random points, on halfspaces laid THROUGH points and +-0.5e-9 /
+    +-1.5e-9 beside them (inside and just outside the on-plane band), and on a real polyhedron with directions and freed slots.
+    (3) A batched run of a SURVEY 8c golden with the matrix kernel switched on ends in the reference's polyhedron."""
+    import ctypes
+    from bensolve_amd._lib import load_library, check
+    lib = load_library()
+    for dim in (2, 3, 4, 5, 8, 10):
+        mism = ctypes.c_long(-1)
+        check(lib.bslv_k1_mfma_selftest(dim, 20000, ctypes.c_ulonglong(dim), ctypes.byref(mism)))
+        assert mism.value == 0, (dim, mism.value)
+
+    def both(G, hps):
+        res = {}
+        for mode in (1, 0):
+            G.debug_set(9, mode)
+            words, anym, _ = G.classify_batch(hps)
+            w2, tc, t1 = G.classify_batch_touch(hps)
+            res[mode] = (words.copy(), anym.copy(), w2, tc, t1)
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a, b)
+        return res[1]
+
+    try:
+        for q, nv, B in ((5, 200_000, 96), (3, 50_000, 40), (8, 30_000, 16), (5, 39, 192), (4, 1000, 512)):
+            G = PolyEngine(q)
+            G.bench_fill(nv, 3)
+            X = G.dump()["X"]
+            rng = np.random.default_rng(q)
+            H = rng.normal(size=(B, q))
+            alpha = rng.normal(size=B) * 0.3
+            for b in range(0, B, 2):                           # every other halfspace passes (nearly) through a point
+                p = X[rng.integers(nv)]
+                alpha[b] = H[b] @ p + (0.0, 0.5e-9, -0.5e-9, 1.5e-9, -1.5e-9)[(b // 2) % 5]
+            r = both(G, np.hstack([H, alpha[:, None]]))
+            G.close()
+            assert (((r[0][0] >> np.uint64(0)) & np.uint64(3)) == 2).any()      # the band is exercised
+        # a real polyhedron: directions (measured against 0), freed slots, few elements
+        name = "tangent_q5_N200"
+        q, v2h, apex, init_after = [int(x) for x in _GOLD_L[name + "/in_meta"]]
+        vals, ideals = _GOLD_L[name + "/in_vals"], list(_GOLD_L[name + "/in_ideals"])
+        for extra in (0, 40):
+            G = PolyEngine(q, v2h)
+            for k in range(init_after + extra):
+                G.add(vals[k], ideals[k])
+                if k + 1 == init_after:
+                    assert G.init() == 0
+            d = G.dump()
+            assert (d["pi"] & d["pu"]).any() if extra == 0 else (d["pu"] == 0).any()      # live directions / freed slots
+            rng = np.random.default_rng(extra)
+            for B in (16, 100, 192):
+                both(G, np.hstack([rng.normal(size=(B, G.d)), rng.normal(size=(B, 1))]))
+            G.close()
+        # batched run with the matrix kernel
+        G = PolyEngine(q, v2h)
+        G.debug_set(9, 1)
+        for k in range(init_after):
+            G.add(vals[k], ideals[k])
+        assert G.init() == 0
+        G.add_cuts(vals[init_after:], ideals[init_after:])
+        G.dual_adjacency()
+        can = ph.canonical(G.dump())
+        G.close()
+        ph.assert_matches_large_golden(can, _GOLD_L, _META_L, name)
+    finally:
+        G = PolyEngine(3)
+        G.debug_set(9, 0)
+        G.close()
