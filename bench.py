@@ -223,7 +223,12 @@ def main():
                      "note": "a single cut runs on ~10^2 workgroups for ~50 us (dependent chain of 3 launches); a multi-cut pass applies all independent cuts of a batch in one sweep"}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload.startswith("S-degenerate") and not args.cpu_lps:
+        # the oracle's plain dual simplex does not finish ONE cold LP of this family at full size in minutes (45 k pivots at
+        # q=6, n=500): no CPU figure instead of a bench that never returns.  --cpu-lps N forces the attempt.
+        cpu = {"value": None, "unit": "LPs/s", "cores": 1, "kind": "port",
+               "sample": "not measured: oracle/lp_dense.c needs > 10 minutes for the cold start of one 4000 x 2000 LP of the degenerate family (no bound flipping, no perturbation); --cpu-lps N forces it"}
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_api
         # same stage on both sides: the CPU oracle first works through `warm` LPs untimed-by-us (its cold solve and the first,

@@ -43,6 +43,8 @@ constexpr double TOL_BND = 1e-9, TOL_DJ = 1e-9, TOL_PIV = 1e-9;
 constexpr double BIG = 1e7;   // artificial bound for dual-infeasible free columns
 constexpr int TR = 32;        // tableau rows per workgroup in k_flush / k_init
 constexpr int NT = 256;       // threads per workgroup
+constexpr int FLIP_INCR_MAX = 48;   // bound switches of one iteration that beta follows by a vector update (more: recomputed in the pass)
+constexpr int NT_BIG = 1024;  // k_flush where its LDS footprint leaves room for one or two workgroups per CU
 
 struct PivDesc { int r, q; double p, pbeta, enter_val; };
 
@@ -72,7 +74,7 @@ struct BatchView {
     double *dper;               // [B][ld]       perturbed reduced costs (the ratio tests use them while PF_PERT is set)
     int *pflags, *stall;        // PF_* bits; consecutive degenerate pivots
     const double *cvals;        // [B][ccnt] objective coefficients (objmode)
-    int *xstat;                 // [4] of the batch: iterations with bound switches, perturbations, primal steps, removals that left wrong signs
+    int *xstat;                 // [5] of the batch: iterations with bound switches, perturbations, primal steps, removals that left wrong signs, switch iterations carried into beta without a pass
     int *work, *nwork;      // LPs whose tableau k_flush passes over in a round (k_list_pending), their number per round
 };
 
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
     // smallest variable id among the infeasible rows, exact minimum ratio with smallest id among ties
     const bool bland = Bv.iters[b] >= L.bland_after && !(pf & PF_PERT);     // (perturbed costs break the ties themselves)
     int r = -1, q = -1, nflip = 0;
+    bool incr = false;                       // bound switches of this iteration already carried into beta
     bool below = false, have_col = false;
 
     if (EXT && (pf & PF_PRIMAL)) {
@@ -593,8 +596,28 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
         // recomputed from the new tableau (MODE_REFRESH below), before the LP selects again
         for (int k = tid; k < nflip; k += NT) {
             const int j = sidx[k], kv = nh[j];
-            if (nstat[j] == NS_L) { nstat[j] = NS_U; xN[j] = UP(L, Bv, b, kv); }
-            else { nstat[j] = NS_L; xN[j] = LO(L, Bv, b, kv); }
+            const double lo = LO(L, Bv, b, kv), up = UP(L, Bv, b, kv);
+            if (nstat[j] == NS_L) { nstat[j] = NS_U; xN[j] = up; skey[k] = up - lo; }
+            else { nstat[j] = NS_L; xN[j] = lo; skey[k] = lo - up; }
+        }
+        // A few switches: beta follows them as a vector update, beta_i += sum_k T_i,j(k) * delta_k over the columns j(k) of the
+        // tableau as it is after the pending pivots (row M = the reduced costs, row r = the row at hand) -- nflip strided column
+        // reads instead of a pass over the whole tableau, and the LP keeps selecting (up to KP pivots per pass as without
+        // switches).  Many switches (a cold start walks hundreds of breakpoints): the pass with MODE_REFRESH as before.
+        // beta is recomputed from the tableau before any status is reported (verified), so the update cannot end in a result.
+        if (nflip > 0 && nflip <= FLIP_INCR_MAX) {
+            __syncthreads();
+            for (int i = tid; i <= M; i += NT) {
+                double acc = 0.0;
+                for (int k = 0; k < nflip; k++) {
+                    const int j = sidx[k];
+                    const double t = i == M ? drow[j] : (i == r ? row[j] : virt_entry(T0[(size_t)i * ld + j], i, j, np, pd, prow0, pcol0, ld, L.Mp1p));
+                    acc = fma(t, skey[k], acc);
+                }
+                beta[i] += acc;
+            }
+            incr = true;
+            __syncthreads();
         }
     }
     }
@@ -620,6 +643,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
                                  below ? lo - br : br - up, q, kn, trq, dwork[q], fabs(dwork[q] / trq), nflip, beta[M], bland ? " bland" : "", (pf & PF_PERT) ? " perturbed" : "");
         if constexpr (EXT) {
             if (nflip > 0) atomicAdd(&Bv.xstat[0], 1);
+            if (incr) atomicAdd(&Bv.xstat[4], 1);
             if (have_col) atomicAdd(&Bv.xstat[2], 1);
             if (!have_col) {
                 // dual degenerate stalling: perturb the costs from the next selection on
@@ -631,7 +655,7 @@ __global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int
                 Bv.stall[b] = stl;
             }
         }
-        Bv.mode[b] = nflip > 0 ? MODE_REFRESH : MODE_PIVOT;
+        Bv.mode[b] = (nflip > 0 && !incr) ? MODE_REFRESH : MODE_PIVOT;
         Bv.verified[b] &= 2;
         Bv.iters[b] += 1;
     }
@@ -686,9 +710,13 @@ __global__ void k_after_flush(BatchView Bv, int it)
 //      Algorithmic traffic of one pass: one read + one write of the tableau, whatever the number of pending pivots. ----
 //      wide != 0 (rows of more than ~3000 columns: KP pivot rows do not fit in LDS): the pivot rows are read from global
 //      memory instead -- every row tile of an LP reads the same KP rows, which the L2 / MALL serve after the first tile. ----
+//      Workgroup size: NT threads, or NT_BIG where the KP pivot rows take so much LDS that fewer than 3 workgroups fit on a CU
+//      (rows of more than ~850 columns): with 4 waves per CU the pass is latency-bound (S-degenerate, 2011 columns: 1.8 TB/s);
+//      16 waves share one copy of the rows instead.
 template <bool WIDE>
-__global__ __launch_bounds__(NT) void k_flush(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8, 16 or 32 */)
+__global__ __launch_bounds__(NT_BIG) void k_flush(LpView L, BatchView Bv, int it, int tiles, int tr /* rows per work item: 8 .. 128 */)
 {
+    const int NT = (int)blockDim.x;
     extern __shared__ double s_rows[];           // KP pivot rows
     __shared__ PivDesc s_pd[KP];
     const int nitems = Bv.nwork[it] * tiles;
@@ -818,7 +846,7 @@ struct bslv_lpq {
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
     double *dper_d = nullptr; int *pflags_d = nullptr, *stall_d = nullptr, *xstat_d = nullptr;
     double *cvals_d = nullptr; size_t cvals_cap = 0;     // objective coefficients of solve_batch_obj
-    long last_ext[4] = {0, 0, 0, 0};
+    long last_ext[5] = {0, 0, 0, 0, 0};
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
     size_t select_lds_max = 64 * 1024; // dynamic LDS of k_select<true> (candidate sort of the bound flipping ratio test)
     bool has_boxed = false;            // some variable outside the per-LP range has two finite, non-artificial bounds
@@ -866,7 +894,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     HIP_TRY(hipMalloc(&h->dper_d, (size_t)cap * h->L.ld * sizeof(double)));
     HIP_TRY(hipMalloc(&h->pflags_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->stall_d, cap * sizeof(int)));
-    if (!h->xstat_d) HIP_TRY(hipMalloc(&h->xstat_d, 4 * sizeof(int)));
+    if (!h->xstat_d) HIP_TRY(hipMalloc(&h->xstat_d, 8 * sizeof(int)));
     HIP_TRY(hipMalloc(&h->npend_d, cap * sizeof(int)));
     HIP_TRY(hipMalloc(&h->flushed_d, cap * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->status_h, cap * sizeof(int)));
@@ -1106,7 +1134,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         if (need > h->nworkcap) { if (h->nwork_d) (void)hipFree(h->nwork_d); h->nwork_d = nullptr; HIP_TRY(hipMalloc(&h->nwork_d, need * sizeof(int))); h->nworkcap = need; }
         HIP_TRY(hipMemsetAsync(h->nwork_d, 0, need * sizeof(int), s));
     }
-    HIP_TRY(hipMemsetAsync(h->xstat_d, 0, 4 * sizeof(int), s));
+    HIP_TRY(hipMemsetAsync(h->xstat_d, 0, 8 * sizeof(int), s));
     BatchView bv = bview(h);
     bv.cvals = h->cvals_d;
     const int tiles = (L.Mp1 + TR - 1) / TR;
@@ -1119,6 +1147,8 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     hipLaunchKernelGGL(k_init, dim3(tiles, B), dim3(NT), 0, s, L, bv, B);
     HIP_TRY(hipGetLastError());
     const size_t lds = wide ? 0 : (size_t)KP * L.ld * sizeof(double);
+    // (160 KB of LDS per CU: three workgroups of NT threads need lds <= ~53 KB)
+    const bool big_flush = getenv("BSLV_FLUSH_NT") ? atoi(getenv("BSLV_FLUSH_NT")) > NT : lds > 53 * 1024;
     // bound flipping ratio test only where a variable has two finite, non-artificial bounds
     bool bfrt = h->has_boxed || L.objmode;        // (the primal steps live in the extended selection)
     if (!bfrt && L.vcnt > 0)
@@ -1159,10 +1189,15 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
                 HIP_TRY(hipEventRecord(h->evpool[nev].first, s));
             }
             // few LPs left: smaller row tiles keep >= ~2k workgroups in flight
-            const int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : 8);
+            int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : 8);
+            if (big_flush) {                                            // 16 waves per workgroup: at least one row per wave, more where the batch still fills the chip
+                const long rows = (long)running * L.Mp1;
+                tr = rows >= 2048L * 128 ? 128 : rows >= 2048L * 64 ? 64 : rows >= 2048L * 32 ? 32 : 16;
+            }
             const int ntile = (L.Mp1 + tr - 1) / tr;
-            if (wide) hipLaunchKernelGGL(k_flush<true>, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), 0, s, L, bv, it, ntile, tr);
-            else hipLaunchKernelGGL(k_flush<false>, dim3(std::min(running * ntile, h->upd_grid)), dim3(NT), lds, s, L, bv, it, ntile, tr);
+            const int fnt = big_flush ? NT_BIG : NT;
+            if (wide) hipLaunchKernelGGL(k_flush<true>, dim3(std::min(running * ntile, h->upd_grid)), dim3(fnt), 0, s, L, bv, it, ntile, tr);
+            else hipLaunchKernelGGL(k_flush<false>, dim3(std::min(running * ntile, h->upd_grid)), dim3(fnt), lds, s, L, bv, it, ntile, tr);
             if (h->profile) { HIP_TRY(hipEventRecord(h->evpool[nev].second, s)); nev++; }
             hipLaunchKernelGGL(k_after_flush, dim3((running + 255) / 256), dim3(256), 0, s, bv, it);
         }
@@ -1197,7 +1232,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         if (iters) memcpy(iters, itv.data(), B * sizeof(int));
     }
     h->last_iters = it;
-    { int xs[4]; HIP_TRY(hipMemcpy(xs, h->xstat_d, sizeof xs, hipMemcpyDeviceToHost)); for (int k = 0; k < 4; k++) h->last_ext[k] = xs[k]; }
+    { int xs[5]; HIP_TRY(hipMemcpy(xs, h->xstat_d, sizeof xs, hipMemcpyDeviceToHost)); for (int k = 0; k < 5; k++) h->last_ext[k] = xs[k]; }
     if (h->profile) {
         double ms = 0;
         for (size_t e = 0; e < nev; e++) { float t = 0; (void)hipEventElapsedTime(&t, h->evpool[e].first, h->evpool[e].second); ms += t; }
@@ -1254,6 +1289,7 @@ int bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out)
 }
 
 long bslv_lpq_last_passes(const bslv_lpq *h) { return h ? h->last_passes : 0; }
+long bslv_lpq_last_flip_updates(const bslv_lpq *h) { return h ? h->last_ext[4] : 0; }
 int bslv_lpq_last_ext_stats(const bslv_lpq *h, long out[4])
 {
     if (!h || !out) return BSLV_E_ARG;

@@ -93,6 +93,10 @@ CONFIGS = {
     "S-small": lambda: covering_vlp(200, 100, 3, 1),
     "S-mid": lambda: covering_vlp(1000, 500, 5, 2),
     "S-degenerate": lambda: degenerate_vlp(4000, 2000, 10, 3),
+    # the same LPs (4000 x 2000 before the presolve) with q reduced until the run TERMINATES on one GPU ("reduce q and
+    # record the change"): q = 4 ends after 1.7e5 LPs / 3.3e4 facets; q = 5 at n = 200 after 4.2e6 LPs / 7.2e5 facets
+    "S-degenerate-q4": lambda: degenerate_vlp(4000, 2000, 4, 3),
+    "S-degenerate-q5-n200": lambda: degenerate_vlp(400, 200, 5, 3),
 }
 
 

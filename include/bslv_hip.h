@@ -102,6 +102,9 @@ long bslv_lpq_last_passes(const bslv_lpq *h);
  * bound (long-step ratio test), [1] cost perturbations switched on, [2] primal simplex steps, [3] perturbation removals
  * that left reduced costs of the wrong sign (what the bound switches / primal steps then repaired) */
 int  bslv_lpq_last_ext_stats(const bslv_lpq *h, long out[4]);
+/* of the iterations with bound switches (out[0] above): those whose switches were carried into beta by a vector update, i.e.
+ * without a pass over the tableau (at most 48 switches in the iteration) */
+long bslv_lpq_last_flip_updates(const bslv_lpq *h);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Polyhedron engine  (replaces bslv_poly.h:90-118)

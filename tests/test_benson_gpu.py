@@ -42,7 +42,8 @@ def test_phase2_sets_match_oracle(m, n, q, seed, batch):
     assert tot["lps"] >= len(exp["X"]) - q
 
 
-@pytest.mark.parametrize("m,n,q,batch", [(24, 12, 3, 8), (60, 30, 3, 32), (60, 30, 4, 64), (120, 60, 4, 128), (60, 30, 5, 128), (40, 20, 6, 128)])
+@pytest.mark.parametrize("m,n,q,batch", [(24, 12, 3, 8), (60, 30, 3, 32), (60, 30, 4, 64), (120, 60, 4, 128), (60, 30, 5, 128), (40, 20, 6, 128),
+                                         (200, 100, 4, 512), (400, 200, 4, 1024)])
 def test_phase2_degenerate_family_matches_oracle(m, n, q, batch):
     """BASELINE.json configs[4] (S-degenerate: unit cube + integer cover rows, integer lattice objectives, free columns) at
     sizes the CPU oracle finishes: massively dual-degenerate LPs (ties in every ratio test, Bland's rule after the
@@ -62,6 +63,9 @@ def test_phase2_degenerate_family_matches_oracle(m, n, q, batch):
     eng.close()
     ph.assert_benson_results_agree(got, exp)
     assert len(exp["X"]) >= 30
+    # (400, 200, 4): 18 959 vertices, the largest member the sequential CPU oracle finishes in ~2 minutes -- the independent check
+    # "at size" for the family; S-degenerate itself terminates on the GPU with q reduced to 4 at full n, m (DESIGN.md 5,
+    # profiles/r02_sdegenerate_termination.json), where no CPU path of this repository finishes
 
 
 def test_s_small_complete_run_matches_oracle():
