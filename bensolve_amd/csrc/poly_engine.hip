@@ -1250,10 +1250,10 @@ __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned lo
 constexpr int PTI = 8;
 __global__ __launch_bounds__(PB) void k_pair_flags_tiled(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum,
                                                           const int *fm_cnt, const int *fm_off, const int *fm_list /* NULL: scan all elements */,
-                                                          int *nzlist, int *nzcount)
+                                                          int *nzlist, int *nzcount, int gy0 /* first row group of this launch (a rank's share of the pair space) */)
 {
     extern __shared__ unsigned long long s_t[];       // PTI x W row words | W x (PB + PTI) column words | 4 x W (one M per wave)
-    const int i0 = blockIdx.y * PTI, c = blockIdx.x;
+    const int i0 = ((int)blockIdx.y + gy0) * PTI, c = blockIdx.x;
     const int jbase = i0 + 1 + c * PB;
     if (i0 >= nm - 1 || jbase >= nm) return;
     const int CW = PB + PTI;
@@ -2506,6 +2506,8 @@ struct bslv_poly {
     Tri *bsum = nullptr; int bsumcap = 0;
     Tri *bsum2 = nullptr; size_t bsum2cap = 0;
     int *fm_cnt = nullptr, *fm_list = nullptr; size_t fmcap = 0, fmlistcap = 0; int fm_min = 4096; long n_fm = 0; bool member_lists = true;
+    // multi-GPU: pair space of large facets dealt to the ranks (k2_multi).  Below ~3e4 elements the two all-gathers cost more than the pair tests
+    int shard_min = 32768; long n_sharded = 0; int2 *shard_e = nullptr; size_t shardcap = 0;
     int *nzlist = nullptr; size_t nzcap = 0;         // pair blocks with an adjacent pair (+ their count behind the list)      // facet-major member lists of a large new facet (k_fm_*)       // chunk totals of the two-level scan (k_scan_chunks)
     Tri *totals = nullptr;            // device, 4 entries
     int *counters = nullptr;          // device, 4 ints
@@ -2733,7 +2735,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     const int W = (int)((std::min<long long>(len_ub, nranks) + 63) / 64);
     if ((size_t)W * nm > h->bitscap) { size_t nc = std::max((size_t)W * nm, h->bitscap * 2); if ((rc = grow(&h->bits, 0, nc, s))) return rc; h->bitscap = nc; }
     const size_t lds_bits = (size_t)W * 5 * sizeof(unsigned long long);
-    bool used_list = false;
+    bool used_list = false, shard = false;
     if (lds_bits <= 48 * 1024) {
         HIP_TRY(hipMemsetAsync(h->nlocal, 0, sizeof(int), s));
         const int nbm = (nm * LPM + PB - 1) / PB;
@@ -2761,10 +2763,28 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
             hipLaunchKernelGGL(k_fm_scan, dim3(1), dim3(1024), 0, s, (const int *)h->fm_cnt, h->fm_cnt + nf, h->fm_cnt + 2 * nf, nf);
             hipLaunchKernelGGL(k_fm_fill, dim3(nbw), dim3(PB), 0, s, (const unsigned long long *)h->bits, nm, W, h->fm_cnt + 2 * nf, h->fm_list);
         }
-        if (tiled)
-            hipLaunchKernelGGL(k_pair_flags_tiled, dim3((unsigned)((nm - 1 + PB - 1) / PB), (unsigned)ngroups), dim3(PB), lds_tiled, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
+        if (tiled) {
+            // Multi-GPU: the PAIR SPACE of a large facet is dealt to the ranks -- contiguous row groups of equal pair
+            // count -- every rank tests its share, and the adjacent pairs found (a few per element, not the nm^2 / 2 flags) are
+            // all-gathered and appended in rank order = in the order of the virtual pair blocks, i.e. the edge list is the one a
+            // single GPU writes.  Everything else of the cut stays replicated.
+            int g0 = 0, g1 = ngroups;
+            const int world = bslv_dist_world(), rank = bslv_dist_rank();
+            shard = world > 1 && nm >= h->shard_min;
+            if (shard) {
+                const double total = 0.5 * (double)(nm - 1) * (double)nm;
+                auto before = [&](int g) { const double r = std::min((double)g * PTI, (double)(nm - 1)); return r * (double)(nm - 1) - 0.5 * r * (r - 1.0); };   // pairs in the rows of groups < g
+                auto bound = [&](int k) { if (k <= 0) return 0; if (k >= world) return ngroups; int lo = 0, hi = ngroups; const double want = total * k / world;
+                                          while (lo < hi) { const int mid = (lo + hi) / 2; if (before(mid) < want) lo = mid + 1; else hi = mid; } return lo; };
+                g0 = bound(rank); g1 = bound(rank + 1);
+                HIP_TRY(hipMemsetAsync(h->bsum, 0, (size_t)nbp * sizeof(Tri), s));          // the blocks of the other ranks: no pair
+                h->n_sharded++;
+            }
+            if (g1 > g0)
+            hipLaunchKernelGGL(k_pair_flags_tiled, dim3((unsigned)((nm - 1 + PB - 1) / PB), (unsigned)(g1 - g0)), dim3(PB), lds_tiled, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
                                fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr,
-                               h->nzlist, h->nzlist + h->nzcap);
+                               h->nzlist, h->nzlist + h->nzcap, g0);
+        }
         else {
             // one-dimensional grid of pair blocks: at most 2^32 work-items (the runtime wraps a larger grid silently)
             if ((long long)nbp * PB >= (1ll << 32)) { set_error("new facet has too many elements (%d) for the one-dimensional pair launch", nm); return BSLV_E_CAPACITY; }
@@ -2789,6 +2809,36 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     HIP_TRY(hipGetLastError());
     if ((rc = wait_mail(h, 2, seq))) return rc;
     const Tri tp = h->mail_h[2].t;
+    if (shard) {
+        // this rank's pairs into a staging list, counts and pairs all-gathered (8 bytes per pair, carried as the bit pattern of a double)
+        const int world = bslv_dist_world();
+        if ((size_t)tp.a > h->shardcap) { const size_t nc = std::max<size_t>((size_t)tp.a, std::max<size_t>(4096, h->shardcap * 2)); if ((rc = grow(&h->shard_e, 0, nc, s))) return rc; h->shardcap = nc; }
+        if (tp.a > 0)
+            hipLaunchKernelGGL(k_pair_emit_list, dim3(4096), dim3(PB), 0, s, h->members, nm, (const int *)h->nzlist, (const int *)(h->nzlist + h->nzcap), (const unsigned char *)h->pflag,
+                               (const Tri *)h->bsum, h->shard_e, 0, (int *)nullptr);
+        HIP_TRY(hipGetLastError());
+        std::vector<double> cnt_all((size_t)world), mine((size_t)std::max(tp.a, 1));
+        if (tp.a > 0) HIP_TRY(hipMemcpyAsync(mine.data(), h->shard_e, (size_t)tp.a * sizeof(int2), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const double my_cnt = (double)tp.a;
+        if ((rc = bslv_dist_allgather(&my_cnt, cnt_all.data(), 1))) return rc;
+        long long total = 0; int maxc = 0;
+        for (int r = 0; r < world; r++) { total += (long long)cnt_all[r]; maxc = std::max(maxc, (int)cnt_all[r]); }
+        if (total > 0) {
+            if ((long long)h->ne + total > 0x3FFFFF00ll) { set_error("polyhedron too large: more than 2^30 edges"); return BSLV_E_CAPACITY; }
+            mine.resize((size_t)maxc, 0.0);
+            std::vector<double> all((size_t)maxc * world), packed((size_t)total);
+            if ((rc = bslv_dist_allgather(mine.data(), all.data(), maxc))) return rc;
+            size_t at = 0;
+            for (int r = 0; r < world; r++) { const size_t c = (size_t)cnt_all[r]; memcpy(packed.data() + at, all.data() + (size_t)r * maxc, c * sizeof(double)); at += c; }
+            if ((rc = ensure_ecap(h, (int)(h->ne + total)))) return rc;
+            HIP_TRY(hipMemcpyAsync(h->E[h->ecur] + h->ne, packed.data(), (size_t)total * sizeof(int2), hipMemcpyHostToDevice, s));
+            if (h->EP[h->ecur]) HIP_TRY(hipMemsetAsync(h->EP[h->ecur] + h->ne, 0xFF, (size_t)total * sizeof(int), s));     // (-1: no parent, as k_pair_emit_list writes)
+            HIP_TRY(hipStreamSynchronize(s));                                                                                 // (the host vectors go out of scope)
+            h->ne += (int)total;
+        }
+        return 0;
+    }
     if (tp.a > 0) {
         if ((long long)h->ne + tp.a > 0x3FFFFF00ll) { set_error("polyhedron too large: more than 2^30 edges"); return BSLV_E_CAPACITY; }
         if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
@@ -3272,7 +3322,7 @@ void bslv_poly_destroy(bslv_poly *h)
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->fm_cnt); fr(h->fm_list); fr(h->nzlist); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
-    fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
+    fr(h->shard_e); fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->rounds2) { rounds2_free(*h->rounds2); delete h->rounds2; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
@@ -3579,12 +3629,14 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 4: h->fm_min = (int)std::max(2L, value); return 0;
     case 6: h->rounds2_enabled = value != 0; return 0;                  /* device-selected rounds of independent cuts inside a hot chunk */
     case 7: h->chunk_cuts = (int)std::min(4096L, std::max(32L, value)); return 0;    /* cuts classified and applied together */
+    case 10: h->shard_min = (int)std::max(2L, value); return 0;           /* multi-GPU: facets from this size on have their pair space dealt to the ranks */
     case 9: g_k1_mfma = value != 0; return 0;                            /* incidence kernel K1 on the matrix pipe from 16 halfspaces on (1) or the scalar kernel (0, default); process-wide */
     case 8: h->r2_min_cuts = (int)std::max(-1L, value); return 0;        /* rounds go on while they average at least this many cuts (0: until every round holds one cut, -1: always) */
     case 5: h->member_lists = value != 0; return 0;                     /* edges of large facets confirmed through member lists (1) or against all elements (0) */           /* facets from this size on confirm edges through the facet-major member lists (4096) */
     default: return BSLV_E_ARG;
     }
 }
+long bslv_poly_sharded_prunes(const bslv_poly *h) { return h ? h->n_sharded : 0; }
 int bslv_poly_path_stats(const bslv_poly *h, long out[6])
 {
     if (!h || !out) return BSLV_E_ARG;

@@ -104,6 +104,12 @@ class PolyEngine:
         check(self.lib.bslv_poly_rounds2_stats(self.h, out))
         return dict(rounds=out[0], cuts=out[1], chunks=out[2], fallback_prunes=out[3], declined=out[4])
 
+    def sharded_prunes(self):
+        """multi-GPU: adjacency prunes whose pair space was dealt to the ranks"""
+        self.lib.bslv_poly_sharded_prunes.restype = ctypes.c_long
+        self.lib.bslv_poly_sharded_prunes.argtypes = [ctypes.c_void_p]
+        return self.lib.bslv_poly_sharded_prunes(self.h)
+
     def path_stats(self):
         out = (ctypes.c_long * 6)()
         check(self.lib.bslv_poly_path_stats(self.h, out))

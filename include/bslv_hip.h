@@ -134,6 +134,10 @@ long bslv_poly_rounds_run(const bslv_poly *h);
  * queued speculatively, [2] of those declined by the device and rerun, [3] prunes redone by the multi-kernel path,
  * [4] cuts applied one at a time, [5] multi-kernel prunes that confirmed their edges through facet-major member lists */
 int  bslv_poly_path_stats(const bslv_poly *h, long out[6]);
+/* multi-GPU (4a): adjacency prunes whose pair space was dealt to the ranks (facets of at least 32768 elements; bslv_poly_debug_set
+ * key 10 changes the threshold): every rank tests a contiguous share of the rows, the adjacent pairs found are all-gathered and
+ * appended in rank order, which is the order a single GPU writes them in */
+long bslv_poly_sharded_prunes(const bslv_poly *h);
 /* test hook, same switches as the BSLV_* environment variables but at run time: key 0 dynamic LDS bytes of the one-workgroup
  * prune (64 forces the multi-kernel prune), 1 speculative launch on/off, 2 hot mode on/off, 3 CROSS_UB, 4 size of a new facet
  * from which the multi-kernel prune builds facet-major member lists (default 4096), 5 member lists on/off, 6 device-selected

@@ -56,6 +56,18 @@ def test_rccl_transport_single_rank():
         dist_finalize()
 
 
+def _problem(args):
+    return synth.degenerate_vlp(*args[1:5]) if args[0] == "degenerate" else synth.covering_vlp(*args)
+
+
+def _force_large_facet_path(eng, shard):
+    """every adjacency prune through the multi-kernel path with the row-tiled pair kernel (as for facets of 10^4..10^5 elements),
+    and with `shard` its pair space dealt to the ranks"""
+    eng.poly_call("debug_set", 0, 64)        # k2_fused's LDS too small for any facet: multi-kernel prune
+    eng.poly_call("debug_set", 4, 2)         # every facet 'large': tiled pair kernel, member lists
+    eng.poly_call("debug_set", 10, 2 if shard else 1 << 30)
+
+
 def _rank_worker(rank, world, port, args, batch, out):
     import torch
     import torch.distributed as dist
@@ -64,21 +76,26 @@ def _rank_worker(rank, world, port, args, batch, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     dist_init_callback(dist)
-    prob = synth.covering_vlp(*args)
+    prob = _problem(args)
     eng = BensonEngine(prob, eps=1e-9, pool_slots=512)
+    if args[0] == "degenerate":
+        _force_large_facet_path(eng, len(args) < 6 or args[5])
     assert eng.start() == 0
     eng.run(batch)                      # bslv_benson_step routes to bslv_benson_step_dist once a transport is set
     eng.poly_call("dual_adjacency")
     d = eng.poly_dump()
     tot = eng.totals()
-    out[rank] = dict(d, lps=tot["lps"], local_pivots=tot["pivots"])
+    out[rank] = dict(d, lps=tot["lps"], local_pivots=tot["pivots"], sharded=eng.poly_call("sharded_prunes"), fallbacks=eng.poly_call("path_stats")["prune_fallbacks"])
     eng.close()
     dist_finalize()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("args,batch", [((30, 15, 3, 5), 32), ((40, 20, 4, 9), 128)])
+@pytest.mark.parametrize("args,batch", [((30, 15, 3, 5), 32), ((40, 20, 4, 9), 128), (("degenerate", 60, 30, 5, 3), 128)])
 def test_two_ranks_through_the_c_step(args, batch):
+    """(the third case: a member of the degenerate family with every adjacency prune forced through the large-facet path and its
+    PAIR SPACE dealt to the two ranks -- SURVEY 8e -- : the adjacent pairs are all-gathered and appended in rank order, so the
+    edge list, and with it everything else, is bit-identical to the run in which every rank tests all pairs)"""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
@@ -88,11 +105,22 @@ def test_two_ranks_through_the_c_step(args, batch):
     for k in ("pu", "pi", "ps", "E", "I", "X", "Y", "du", "DE"):
         assert np.array_equal(d0[k], d1[k]), "replicas diverged in " + k
     assert d0["lps"] == d1["lps"] and d0["local_pivots"] > 0 and d1["local_pivots"] > 0        # both ranks solved LPs
-    prob = synth.covering_vlp(*args)
+    prob = _problem(args)
     eng = BensonEngine(prob, eps=1e-9, pool_slots=512)
+    if args[0] == "degenerate":
+        _force_large_facet_path(eng, False)
     assert eng.start() == 0
     eng.run(batch)
     eng.poly_call("dual_adjacency")
-    single = ph.canonical(eng.poly_dump(), decimals=6)
+    sd = eng.poly_dump()
+    single = ph.canonical(sd, decimals=6)
     eng.close()
-    ph.assert_benson_results_agree(ph.canonical(dict((k, d0[k]) for k in ("d", "pu", "pi", "ps", "X", "du", "di", "Y", "E", "I", "DE")), decimals=6), single)
+    if args[0] == "degenerate":
+        assert d0["sharded"] > 50 and d0["sharded"] == d1["sharded"] >= d0["fallbacks"], (d0["sharded"], d0["fallbacks"])     # (+ the prunes of the rounds)
+        # the same two-rank run with every rank testing the whole pair space: bit-identical polyhedron, slot by slot and edge by edge
+        out2 = mgr.dict()
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        mp.spawn(_rank_worker, args=(2, port, tuple(args) + (False,), batch, out2), nprocs=2, join=True)
+        assert out2[0]["sharded"] == 0
+        for k in ("pu", "pi", "ps", "E", "I", "X", "Y", "du", "DE"):
+            assert np.array_equal(d0[k], out2[0][k]), "sharded prune differs from the replicated prune in " + k
