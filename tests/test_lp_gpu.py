@@ -285,3 +285,64 @@ def test_wide_rows_read_the_pivot_rows_from_global_memory(oracle):
     np.testing.assert_allclose(obj, exp_obj, rtol=RTOL, atol=1e-9)
     _check_identities(model, V, obj, eng.dual(dst, model.w_first, q), eng.primal(dst, model.y_first, q))
     eng.close()
+
+
+def _p2_highs(prob, v):
+    """P2(v) = min z : x in S, P x - z c <= v (c = (1..1)), stated for scipy's HiGHS directly from the problem data --
+    independent of oracle/ and of bensolve_amd.lp.P2Model"""
+    from scipy.optimize import linprog
+    A, P = prob["A"], prob["P"]
+    m, n = A.shape
+    q = P.shape[0]
+    Aub, bub, Aeq, beq = [], [], [], []
+    for i in range(m):
+        t, lo, up = chr(prob["rtype"][i]), prob["rlb"][i], prob["rub"][i]
+        row = np.concatenate([A[i], [0.0]])
+        if t == "s":
+            Aeq.append(row); beq.append(lo)
+        if t in "ld":
+            Aub.append(-row); bub.append(-lo)
+        if t in "ud":
+            Aub.append(row); bub.append(up)
+    for k in range(q):
+        Aub.append(np.concatenate([P[k], [-1.0]])); bub.append(v[k])
+    bounds = []
+    for j in range(n):
+        t, lo, up = chr(prob["ctype"][j]), prob["clb"][j], prob["cub"][j]
+        bounds.append({"f": (None, None), "l": (lo, None), "u": (None, up), "d": (lo, up), "s": (lo, lo)}[t])
+    bounds.append((None, None))
+    c = np.zeros(n + 1); c[n] = 1.0
+    res = linprog(c, A_ub=np.array(Aub), b_ub=np.array(bub), A_eq=np.array(Aeq) if Aeq else None, b_eq=np.array(beq) if Aeq else None,
+                  bounds=bounds, method="highs")
+    assert res.status == 0, res.message
+    return res.fun
+
+
+@pytest.mark.parametrize("name,B", [("S-small", 12), ("S-mid", 8), ("S-degenerate", 4)])
+def test_gpu_lp_matches_highs_at_bench_sizes(name, B):
+    """The LP half against an INDEPENDENT solver at the sizes of BASELINE.json's configurations (the CPU oracle is not in this
+    test): P2(v) of S-small (200 x 100), S-mid (1000 x 500) and S-degenerate (4000 x 2000 as stated; the engine solves the
+    presolved 2021 x 2011 form with boxed columns, long-step ratio test, perturbation) for B points v -- optimal values of the
+    batched GPU dual simplex against scipy's HiGHS on the LP written down from the problem data, at HiGHS' own tolerance."""
+    prob = synth.CONFIGS[name]()
+    folded = synth.fold_singleton_rows(prob) if name == "S-degenerate" else prob
+    model = P2Model(folded)
+    rng = np.random.default_rng(11)
+    n, q = prob["n"], prob["q"]
+    if name == "S-degenerate":
+        V = rng.random((B, n)) @ prob["P"].T + rng.normal(scale=2.0, size=(B, q))
+    else:
+        V = _random_V(model, prob, rng, B)
+    ub = model.ub_for(V)
+    eng = LpEngine.from_model(model, pool_slots=B + 1)
+    eng.reset_slot(0)
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+    assert st[0] == 4
+    src = np.zeros(B, np.int32)
+    dst = np.arange(1, B + 1, dtype=np.int32)
+    st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+    assert np.all(st == 4)
+    obj = eng.obj(dst)
+    eng.close()
+    ref = np.array([_p2_highs(prob, V[b]) for b in range(B)])
+    np.testing.assert_allclose(obj, ref, rtol=1e-7, atol=1e-7)
