@@ -42,6 +42,7 @@ struct bslv_benson {
     bslv_lpq *lp = nullptr;
     bslv_poly *poly = nullptr;
     int pool_slots = 0;
+    int batch_cap = 1 << 30;            // LPs per outer iteration and rank the pool of tableaux can serve
     // tableau slots: 0 = root (kept).  facet -> slot of the LP that produced the cut
     std::vector<int> free_slots;
     std::deque<std::pair<int, int>> parents;          // (facet, slot) in creation order
@@ -171,6 +172,22 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
     for (int j = 0; j < n; j++) { lo[M + j] = clo[j]; up[M + j] = cup[j]; }
     for (int j = n; j < N; j++) { lo[M + j] = -INFINITY; up[M + j] = INFINITY; }
     cost[N] = 1.0;
+    {
+        // The pool has to fit: a slot is the whole (M + 1) x N tableau (ex09 of the reference's suite: 4612 x 36 942 doubles = 1.36 GB).
+        // The number of slots is cut to 70 % of the free device memory, and the LPs per outer iteration follow (a quarter of the
+        // pool: a child needs its parent's slot and its own) -- 288 GB hold 140 such tableaux.
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const size_t ld = ((size_t)N + 2 + 1) & ~(size_t)1;
+            const size_t slot = ((size_t)M + 2) * ld * sizeof(double) + ((size_t)M * 2 + (size_t)N * 4 + ld) * 8;
+            const size_t fit = (size_t)(0.7 * (double)fr) / std::max<size_t>(slot, 1);
+            if ((size_t)pool_slots > fit) {
+                if (fit < 8) { set_error("bslv_benson_create: a tableau of %zu MB does not fit 8 times into the %zu MB of free device memory", slot >> 20, fr >> 20); bslv_benson_destroy(h); return BSLV_E_CAPACITY; }
+                pool_slots = (int)fit;
+                h->batch_cap = std::max(1, (pool_slots - 4) / 4);       // (only where memory cut the pool: callers that sized it themselves keep their batch)
+            }
+        }
+    }
     int rc = bslv_lpq_create(&h->lp, M, N, L.data(), lo.data(), up.data(), cost.data(), m + q, r, pool_slots);
     if (rc) { bslv_benson_destroy(h); return rc; }
     rc = bslv_poly_create(&h->poly, q, 1 /* lowerV2upperH */, c);
@@ -256,6 +273,7 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
     const int q = h->q;
     bslv_benson::BatchCtx &B = h->ctx[ctx];
     h->rank = rank; h->world = world;
+    max_batch = (int)std::min<long long>(max_batch, (long long)h->batch_cap * world);          // (what the pool of tableaux can serve, see bslv_benson_create_ex)
     int rc, cnt = 0;
     for (;;) {
         const int pol = h->policy == 3 ? 1 : h->policy;
@@ -435,7 +453,11 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
         std::vector<int> redo;
         if (getenv("BSLV_FORCE_RETRY")) for (int k = 1; k < nl; k += 2) st[k] = BSLV_LP_UNDEFINED;      // test hook: every other LP goes through the retry
         for (int k = 0; k < nl; k++) if (st[k] == BSLV_LP_UNDEFINED) redo.push_back(k);
-        for (int stage = 0; stage < 2 && !redo.empty(); stage++) {
+        for (int stage = 0; stage < 3 && !redo.empty(); stage++) {
+            // stage 2: still no result from the standard basis -- a dual simplex that stalls in degenerate pivots until the iteration
+            // limit (ex09).  The extended selection (cost perturbation + primal clean-up, lp_engine.hip) is switched on for this
+            // engine and stays on: a problem that needed it once needs it for its other LPs too.
+            if (stage == 2) { if ((rc = bslv_lpq_set_extended(h->lp, 1))) return rc; }
             const int nr = (int)redo.size();
             std::vector<int> s2(nr), d2(nr), st2(nr), it2(nr);
             std::vector<double> lo2((size_t)nr * r, -INFINITY), up2((size_t)nr * r);
@@ -443,7 +465,7 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
                 d2[t] = dst[redo[t]];
                 s2[t] = stage == 0 ? 0 : d2[t];
                 memcpy(&up2[(size_t)t * r], &vup[(size_t)redo[t] * r], r * sizeof(double));
-                if (stage == 1 && (rc = bslv_lpq_reset_slot(h->lp, d2[t]))) return rc;
+                if (stage >= 1 && (rc = bslv_lpq_reset_slot(h->lp, d2[t]))) return rc;
             }
             if ((rc = bslv_lpq_solve_batch(h->lp, nr, s2.data(), d2.data(), lo2.data(), up2.data(), st2.data(), it2.data()))) return rc;
             std::vector<int> still;

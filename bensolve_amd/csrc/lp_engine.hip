@@ -850,6 +850,8 @@ struct bslv_lpq {
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
     size_t select_lds_max = 64 * 1024; // dynamic LDS of k_select<true> (candidate sort of the bound flipping ratio test)
     bool has_boxed = false;            // some variable outside the per-LP range has two finite, non-artificial bounds
+    bool force_ext = false;            // extended selection (perturbation, primal clean-up) also without a boxed variable: bslv_lpq_set_extended,
+                                       // and by itself for tableaux of 1 GiB and more (every pivot costs a millisecond there: no stalling)
     size_t flush_lds_max = 64 * 1024;  // dynamic LDS k_flush may use (raised to 144 KB at create when the runtime allows)
     int upd_grid = 32768;             // workgroups of the persistent k_flush (BSLV_UPD_GRID; 1024..32768 measured equal within 2 %)
     int *active_d = nullptr, *active_h = nullptr;       // compacted indices of the LPs still running (device / pinned)
@@ -1019,6 +1021,7 @@ int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double 
     }
     if ((rc = upload_bounds(h, lb, ub))) return fail(rc);
     if ((rc = ensure_batch(h, 64))) return fail(rc);
+    h->force_ext = L.slotT * sizeof(double) >= ((size_t)1 << 30);
     {   // k_flush stages KP pivot rows in LDS: wide problems (N > ~1300) need more than the default 64 KB
         const size_t want = (size_t)KP * h->L.ld * sizeof(double);
         if (want > h->flush_lds_max) {
@@ -1150,7 +1153,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     // (160 KB of LDS per CU: three workgroups of NT threads need lds <= ~53 KB)
     const bool big_flush = getenv("BSLV_FLUSH_NT") ? atoi(getenv("BSLV_FLUSH_NT")) > NT : lds > 53 * 1024;
     // bound flipping ratio test only where a variable has two finite, non-artificial bounds
-    bool bfrt = h->has_boxed || L.objmode;        // (the primal steps live in the extended selection)
+    bool bfrt = h->has_boxed || L.objmode || h->force_ext;        // (the primal steps live in the extended selection)
     if (!bfrt && L.vcnt > 0)
         for (size_t k = 0; k < (size_t)B * L.vcnt && !bfrt; k++) bfrt = std::isfinite(vlo[k]) && std::isfinite(vup[k]) && vlo[k] < vup[k];
     if (getenv("BSLV_LP_EXT")) bfrt = atoi(getenv("BSLV_LP_EXT")) != 0;      // test hook: force the extended selection on / off
@@ -1290,6 +1293,16 @@ int bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out)
 
 long bslv_lpq_last_passes(const bslv_lpq *h) { return h ? h->last_passes : 0; }
 long bslv_lpq_last_flip_updates(const bslv_lpq *h) { return h ? h->last_ext[4] : 0; }
+// The extended selection for every LP of this engine from now on (on != 0) or only where a variable is boxed (0, the default
+// below 1 GiB per tableau).  It changes the pivots taken, not the optimal value: used by the callers' retry when the plain
+// dual simplex runs into its iteration limit on a degenerate LP.
+int bslv_lpq_set_extended(bslv_lpq *h, int on)
+{
+    if (!h) { set_error("bslv_lpq_set_extended: bad argument"); return BSLV_E_ARG; }
+    h->force_ext = on != 0;
+    return 0;
+}
+int bslv_lpq_get_extended(const bslv_lpq *h) { return h && h->force_ext; }
 int bslv_lpq_last_ext_stats(const bslv_lpq *h, long out[4])
 {
     if (!h || !out) return BSLV_E_ARG;

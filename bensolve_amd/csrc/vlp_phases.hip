@@ -148,6 +148,13 @@ static int solve0(bslv_lpq *lp, int p, const double *ub, int *st)
         if ((rc = bslv_lpq_reset_slot(lp, 0))) return rc;
         if ((rc = bslv_lpq_solve_batch(lp, 1, &zero, &zero, vlo.data(), ub, st, &it))) return rc;
     }
+    if (*st == BSLV_LP_UNDEFINED && !bslv_lpq_get_extended(lp)) {
+        // still nothing from the standard basis: a dual simplex stalling in degenerate pivots.  The extended selection (cost
+        // perturbation, primal clean-up) from here on, for every LP of this engine
+        if ((rc = bslv_lpq_set_extended(lp, 1))) return rc;
+        if ((rc = bslv_lpq_reset_slot(lp, 0))) return rc;
+        if ((rc = bslv_lpq_solve_batch(lp, 1, &zero, &zero, vlo.data(), ub, st, &it))) return rc;
+    }
     return 0;
 }
 

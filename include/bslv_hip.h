@@ -105,6 +105,13 @@ int  bslv_lpq_last_ext_stats(const bslv_lpq *h, long out[4]);
 /* of the iterations with bound switches (out[0] above): those whose switches were carried into beta by a vector update, i.e.
  * without a pass over the tableau (at most 48 switches in the iteration) */
 long bslv_lpq_last_flip_updates(const bslv_lpq *h);
+/* The extended selection (bound flipping where variables are boxed, cost perturbation against dual-degenerate stalling, primal
+ * clean-up) is compiled in for LPs with a boxed variable and, by itself, for tableaux of 1 GiB and more (ex09 of the reference's
+ * suite: the plain dual simplex stalls there until the iteration limit).  on != 0 switches it on for every later solve of this
+ * engine; the callers' retry does that when an LP is still undefined after the restart from the standard basis
+ * (bslv_lp.c:222-227 is the reference's two-stage retry).  Same optimal values, other pivots. */
+int  bslv_lpq_set_extended(bslv_lpq *h, int on);
+int  bslv_lpq_get_extended(const bslv_lpq *h);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Polyhedron engine  (replaces bslv_poly.h:90-118)

@@ -162,3 +162,34 @@ def test_cli_solution_files(tmp_path, m, n, q, seed, bounded, alg):
     np.testing.assert_allclose(U.sum(axis=1), Ys[:, -1], rtol=1e-7, atol=1e-7)      # b = (1..1): dual objective = y*_q
     assert np.all(U @ prob["A"] <= W @ prob["P"] + 1e-7)
     assert "solution:           on" in open(base + ".log").read()
+
+
+def _certified_run(tmp_path, name, eps, timeout):
+    """bensolve_hip -s on an example of the reference's suite, then scripts/check_solution.py: every point of the upper image has a
+    feasible x whose outcome dominates it up to eps in the ordering cone, every point lies in every supporting halfspace of the
+    lower image's vertices and on one of them (geometric duality) -- a certificate that needs no LP solver."""
+    import json
+    import sys
+    vlp = os.path.join(ROOT, "tests", "golden", "ex", name + ".vlp")
+    base = os.path.join(tmp_path, name)
+    r = subprocess.run([CLI, vlp, "-e", repr(eps), "-s", "-o", base], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_solution.py"), vlp, base, repr(eps)], capture_output=True, text=True, timeout=900)
+    cert = json.loads(c.stdout.strip().splitlines()[-1])
+    assert c.returncode == 0 and cert["ok"], cert
+    return cert
+
+
+def test_cli_ex07_at_the_recommended_epsilon_is_certified(tmp_path):
+    """ex07 of the reference's suite (1211 x 1143, q = 3, ordering cone with 3 generators; ex/example07.m:8-9 recommends -e 0.05):
+    all phases on the dense engine, 367 LPs."""
+    cert = _certified_run(tmp_path, "ex07", 0.05, 600)
+    assert cert["points"] > 100 and cert["dual_vertices"] > 50 and cert["dual_cone_generators"] == 3
+
+
+@pytest.mark.skipif(not os.environ.get("BSLV_RUN_EX09"), reason="4 minutes of GPU time: set BSLV_RUN_EX09=1 (profiles/r02_ex09/ holds the round-2 run)")
+def test_cli_ex09_is_certified(tmp_path):
+    """ex09 (4608 x 36 939, 185 856 non-zeros, ordering cone with 6 generators; ex/example09.m: -e 1e-2): the tableau of ONE LP is
+    1.36 GB; the pool is cut to what fits into the free device memory and the extended selection is on from the first LP."""
+    cert = _certified_run(tmp_path, "ex09", 1e-2, 1500)
+    assert cert["points"] >= 10 and cert["dual_cone_generators"] == 6
