@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NT) void k_init(LpView L, BatchView Bv, int B)
     }
 }
 
-// block-wide helpers (NT = 256 = 4 waves)
+// block-wide helpers (for the block they are called from: 4 waves with NT threads, 16 with NT_BIG)
 __device__ __forceinline__ ValIdx block_argmax(ValIdx x, double *sv, int *si)
 {
     x = wave_argmax(x);
@@ -214,8 +214,7 @@ __device__ __forceinline__ ValIdx block_argmax(ValIdx x, double *sv, int *si)
     if (lane == 0) { sv[wave] = x.v; si[wave] = x.i; }
     __syncthreads();
     ValIdx r{sv[0], si[0]};
-#pragma unroll
-    for (int w = 1; w < NT / WAVE; w++) r = better_max(r, ValIdx{sv[w], si[w]});
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) r = better_max(r, ValIdx{sv[w], si[w]});
     return r;
 }
 __device__ __forceinline__ double block_max(double v, double *sv)
@@ -226,8 +225,7 @@ __device__ __forceinline__ double block_max(double v, double *sv)
     if (lane == 0) sv[wave] = v;
     __syncthreads();
     double r = sv[0];
-#pragma unroll
-    for (int w = 1; w < NT / WAVE; w++) r = fmax(r, sv[w]);
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) r = fmax(r, sv[w]);
     return r;
 }
 __device__ __forceinline__ double block_min(double v, double *sv)
@@ -238,8 +236,7 @@ __device__ __forceinline__ double block_min(double v, double *sv)
     if (lane == 0) sv[wave] = v;
     __syncthreads();
     double r = sv[0];
-#pragma unroll
-    for (int w = 1; w < NT / WAVE; w++) r = fmin(r, sv[w]);
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) r = fmin(r, sv[w]);
     return r;
 }
 
@@ -275,11 +272,14 @@ __device__ __forceinline__ double hash01(int k)
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13;
     return (double)(x >> 8) * (1.0 / 16777216.0);
 }
+// Workgroup: NT threads; NT_BIG for rows of 8192 columns and more (ex09: 36 939) -- there an LP's selection is a chain of passes
+// over N entries by ONE workgroup, and four times the threads shorten every pass.
 template <bool EXT>
-__global__ __launch_bounds__(NT) void k_select(LpView L, BatchView Bv, const int *active, int nact, int cap2)
+__global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const int *active, int nact, int cap2)
 {
-    __shared__ double sv[NT / WAVE];
-    __shared__ int si[NT / WAVE];
+    __shared__ double sv[NT_BIG / WAVE];
+    __shared__ int si[NT_BIG / WAVE];
+    const int NT = (int)blockDim.x;
     __shared__ PivDesc s_d;
     __shared__ int s_cnt, s_nboxed, s_stop;
     extern __shared__ unsigned char dyn_sel[];
@@ -1171,6 +1171,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     L.pert_scale = getenv("BSLV_PERT_SCALE") ? atof(getenv("BSLV_PERT_SCALE")) : 1.0;
     // One ROUND = KP lock-step selections on vectors, then one pass over the tableaux of the LPs that have something
     // pending (k_flush).  The status vector is read back every 1, 2, 4, ... rounds.
+    const int sel_nt = L.N >= 8192 ? NT_BIG : NT;
     int it = 0, chunk = 1, running = B;
     for (int b = 0; b < B; b++) h->active_h[b] = b;
     HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, B * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1179,8 +1180,8 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     while (running > 0 && it < L.maxit + 8) {
         for (int c = 0; c < chunk; c++, it++) {
             for (int lev = 0; lev < KP; lev++) {
-                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(NT), sel_lds, s, L, bv, h->active_d, running, cap2);
-                else hipLaunchKernelGGL(k_select<false>, dim3(running), dim3(NT), 0, s, L, bv, h->active_d, running, 0);
+                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(sel_nt), sel_lds, s, L, bv, h->active_d, running, cap2);
+                else hipLaunchKernelGGL(k_select<false>, dim3(running), dim3(sel_nt), 0, s, L, bv, h->active_d, running, 0);
             }
             hipLaunchKernelGGL(k_list_pending, dim3((running + 255) / 256), dim3(256), 0, s, bv, h->active_d, running, it);
             if (h->profile) {
@@ -1192,7 +1193,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
                 HIP_TRY(hipEventRecord(h->evpool[nev].first, s));
             }
             // few LPs left: smaller row tiles keep >= ~2k workgroups in flight
-            int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : 8);
+            int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : (running * tiles * 4 >= 2048 ? 8 : 4));      // (4: one row per wave -- a single LP of a few thousand rows)
             if (big_flush) {                                            // 16 waves per workgroup: at least one row per wave, more where the batch still fills the chip
                 const long rows = (long)running * L.Mp1;
                 tr = rows >= 2048L * 128 ? 128 : rows >= 2048L * 64 ? 64 : rows >= 2048L * 32 ? 32 : 16;

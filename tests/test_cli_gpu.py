@@ -187,7 +187,7 @@ def test_cli_ex07_at_the_recommended_epsilon_is_certified(tmp_path):
     assert cert["points"] > 100 and cert["dual_vertices"] > 50 and cert["dual_cone_generators"] == 3
 
 
-@pytest.mark.skipif(not os.environ.get("BSLV_RUN_EX09"), reason="4 minutes of GPU time: set BSLV_RUN_EX09=1 (profiles/r02_ex09/ holds the round-2 run)")
+@pytest.mark.skipif(not os.environ.get("BSLV_RUN_EX09"), reason="2.3 minutes of GPU time: set BSLV_RUN_EX09=1 (profiles/r02_ex09/ holds the round-2 run)")
 def test_cli_ex09_is_certified(tmp_path):
     """ex09 (4608 x 36 939, 185 856 non-zeros, ordering cone with 6 generators; ex/example09.m: -e 1e-2): the tableau of ONE LP is
     1.36 GB; the pool is cut to what fits into the free device memory and the extended selection is on from the first LP."""
