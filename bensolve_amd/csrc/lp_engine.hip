@@ -272,8 +272,8 @@ __device__ __forceinline__ double hash01(int k)
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13;
     return (double)(x >> 8) * (1.0 / 16777216.0);
 }
-// Workgroup: NT threads; NT_BIG for rows of 8192 columns and more (ex09: 36 939) -- there an LP's selection is a chain of passes
-// over N entries by ONE workgroup, and four times the threads shorten every pass.
+// Workgroup: NT threads; NT_BIG for rows of 1536 columns and more (S-degenerate: 2011, ex09: 36 939) -- an LP's selection is a chain
+// of passes over N entries by ONE workgroup, and four times the threads shorten every pass.
 template <bool EXT>
 __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const int *active, int nact, int cap2)
 {
@@ -1171,7 +1171,9 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     L.pert_scale = getenv("BSLV_PERT_SCALE") ? atof(getenv("BSLV_PERT_SCALE")) : 1.0;
     // One ROUND = KP lock-step selections on vectors, then one pass over the tableaux of the LPs that have something
     // pending (k_flush).  The status vector is read back every 1, 2, 4, ... rounds.
-    const int sel_nt = L.N >= 8192 ? NT_BIG : NT;
+    // (measured, BSLV_SELECT_NT: S-degenerate, 2011 columns, 64 LPs per step: LP phase 67.6 / 52.0 / 46.6 ms with 256 / 512 / 1024 threads;
+    //  S-degenerate-q4 to termination with 256 LPs per step 12.1 -> 10.4 s; same pivots)
+    const int sel_nt = getenv("BSLV_SELECT_NT") ? atoi(getenv("BSLV_SELECT_NT")) : (L.N >= 1536 ? NT_BIG : NT);
     int it = 0, chunk = 1, running = B;
     for (int b = 0; b < B; b++) h->active_h[b] = b;
     HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, B * sizeof(int), hipMemcpyHostToDevice, s));
