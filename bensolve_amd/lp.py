@@ -152,6 +152,11 @@ class LpEngine:
         check(self.lib.bslv_lpq_get_obj(self.h, len(slots), slots.ctypes.data, out.ctypes.data))
         return out
 
+    def set_extended(self, on):
+        """the extended selection (perturbation, primal clean-up) for every later solve of this engine (include/bslv_hip.h)"""
+        self.lib.bslv_lpq_set_extended.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        check(self.lib.bslv_lpq_set_extended(self.h, int(bool(on))))
+
     def last_stats(self):
         it = ctypes.c_int()
         piv = ctypes.c_long()

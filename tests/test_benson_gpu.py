@@ -335,3 +335,18 @@ def test_one_child_per_cut_policy_solves_fewer_redundant_lps():
     nvert = min(len(res[3][0]["X"]), len(res[1][0]["X"]))
     ph.assert_benson_results_agree(res[3][0], res[1][0], allow_sliver=("two batch policies on a q=4 problem with 5e4 vertices: different cut order at eps = POLY_EPS", nvert // 100))
     assert res[3][2] * 2 < res[1][2], "policy 3 should at least halve the redundant LPs: %d vs %d" % (res[3][2], res[1][2])
+
+
+def test_pool_is_cut_to_the_free_device_memory():
+    """bslv_benson_create_ex with a pool that cannot fit (10^6 tableaux of 4 MB): the pool is cut to 70 % of the free device memory
+    and the LPs per outer iteration to a quarter of it, instead of failing in hipMalloc -- what lets ex09 (1.36 GB per tableau) run
+    with the driver's default options.  The run itself is the usual one."""
+    prob = synth.CONFIGS["S-mid"]()
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=1_000_000)
+    pool = eng.pool_stats()["pool"]
+    assert 1000 < pool < 1_000_000, pool
+    assert eng.start() == 0
+    for _ in range(3):
+        s = eng.step(4096)
+    assert s["lps"] > 0 and s["failed"] == 0
+    eng.close()

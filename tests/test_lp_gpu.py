@@ -346,3 +346,29 @@ def test_gpu_lp_matches_highs_at_bench_sizes(name, B):
     eng.close()
     ref = np.array([_p2_highs(prob, V[b]) for b in range(B)])
     np.testing.assert_allclose(obj, ref, rtol=1e-7, atol=1e-7)
+
+
+def test_extended_selection_by_switch_gives_the_same_optima():
+    """bslv_lpq_set_extended (the third stage of the callers' retry, and the default for tableaux of 1 GiB: ex09): the LPs of a
+    covering problem, which the plain dual simplex solves, solved again with cost perturbation / primal clean-up compiled in --
+    same optimal values at 1e-9, the LP identities hold; and the switch is what made the difference (perturbations counted)."""
+    prob = synth.covering_vlp(200, 100, 3, 1)
+    model = P2Model(prob)
+    rng = np.random.default_rng(5)
+    B = 64
+    V = _random_V(model, prob, rng, B)
+    ub = model.ub_for(V)
+    res = {}
+    for ext in (0, 1):
+        eng = LpEngine.from_model(model, pool_slots=B + 1)
+        eng.set_extended(ext)
+        eng.reset_slot(0)
+        st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+        assert st[0] == 4
+        src = np.zeros(B, np.int32); dst = np.arange(1, B + 1, dtype=np.int32)
+        st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+        assert np.all(st == 4)
+        res[ext] = (eng.obj(dst), eng.dual(dst, model.w_first, model.q), eng.primal(dst, model.y_first, model.q))
+        eng.close()
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-9, atol=1e-9)
+    _check_identities(model, V, *res[1])
