@@ -59,18 +59,30 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # REHEARSAL of the N > 1 path on a box with fewer GPUs than ranks (BSLV_BENCH_REHEARSAL=1): the ranks share the devices there
+    # are, torch.distributed runs on gloo and the exchange step on the callback transport -- RCCL itself refuses two ranks on one
+    # device.  Everything else (dealing the batch, the C step, barrier and max over ranks, the JSON line) is the N-GPU code.
+    rehearsal = bool(os.environ.get("BSLV_BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     from bensolve_amd._lib import load_library as _load_lib
     _rc = _load_lib().bslv_set_device(local_rank)      # the engine allocates on the thread's current HIP device: make it explicit
     if _rc != 0:
         raise SystemExit("bslv_set_device(%d) failed: %d" % (local_rank, _rc))
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    transport = "none (one rank)"
+    if world > 1 and rehearsal:
+        dist.init_process_group("gloo")
+        from bensolve_amd.benson import dist_init_callback
+        dist_init_callback(dist)
+        transport = "REHEARSAL: gloo all_gather through bslv_dist_init_callback, ranks share a device"
+    elif world > 1:
         dist.init_process_group("nccl", device_id=device)
         # the data-path collective is the library's own: direct ncclAllGather (RCCL over xGMI) inside bslv_benson_step_dist;
         # torch.distributed hands out the communicator id and does the barrier / max-over-ranks of the timing
         from bensolve_amd.benson import dist_init_rccl
-        dist_init_rccl(dist, device)
+        transport = dist_init_rccl(dist, device)
 
     if args.steps is None:
         args.steps = 3 if args.workload == "S-degenerate" else 8
@@ -174,10 +186,11 @@ def main():
 
     # max over ranks of the elapsed time; sums of the per-rank pivot counts
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        cdev = torch.device("cpu") if rehearsal else device       # (gloo: host tensors)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        agg = torch.tensor([pivots, upd_ms], dtype=torch.float64, device=device)
+        agg = torch.tensor([pivots, upd_ms], dtype=torch.float64, device=cdev)
         allp = [torch.zeros_like(agg) for _ in range(world)]
         dist.all_gather(allp, agg)
         pivots_all = sum(float(a[0]) for a in allp)
@@ -281,7 +294,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s (q=%d, n=%d, m=%d dense covering VLP, seed per SURVEY 8d)" % (args.workload, q, n, m),
                        "lp_rows_cols": [dims["M"], dims["N"]], "rows_folded_by_presolve": dims["rows_folded"], "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": "vertex batch sharded over %d GPU(s), one ncclAllGather of cut records per step (in the library), cut application replicated" % world,
+                       "parallelism": "vertex batch sharded over %d GPU(s), one all-gather of cut records per step (in the library), cut application replicated" % world,
+                       "transport": transport,
                        "lp_poly_overlap": pipe is not None,
                        "tableau_slot_bytes": slot_bytes, "pool_slots": pool_slots, "batch_policy": args.policy or 1, "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,

@@ -184,25 +184,38 @@ class BensonEngine:
 def dist_init_rccl(dist, device):
     """Join the library's own RCCL communicator (include/bslv_hip.h section 4a): rank 0 creates the ncclUniqueId, ONE
     broadcast over `dist` (torch.distributed, any backend) hands it to the others; from then on BensonEngine.step() runs the
-    exchange step inside libbslv_hip.so (bslv_benson_step_dist: direct ncclAllGather over xGMI)."""
+    exchange step inside libbslv_hip.so (bslv_benson_step_dist: direct ncclAllGather over xGMI).
+    Every rank first checks that it can load RCCL and make an id at all; only if ALL can is the communicator created -- a rank
+    that cannot would leave the others waiting in ncclCommInitRank.  Otherwise every rank falls back to the callback transport
+    (the same C step, all-gather through torch.distributed on device tensors).  Returns the name of the transport in use."""
     import torch
     lib = load_library()
     rank, world = dist.get_rank(), dist.get_world_size()
     buf = (ctypes.c_ubyte * 128)()
-    if rank == 0:
+    ok, why = 1, ""
+    try:
         check(lib.bslv_dist_unique_id(buf, 128))
+    except Exception as e:                               # RCCL not loadable on this rank
+        ok, why = 0, str(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        dist_init_callback(dist, device)
+        return "torch.distributed all_gather through bslv_dist_init_callback (RCCL not loadable on some rank%s)" % ((": " + why[:120]) if why else "")
     t = torch.tensor(list(buf), dtype=torch.uint8, device=device)
     dist.broadcast(t, src=0)
     idb = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
     check(lib.bslv_dist_init(rank, world, idb, 128))
+    return "ncclAllGather (RCCL) inside libbslv_hip.so"
 
 
 _cb_keep = []
 
 
-def dist_init_callback(dist):
+def dist_init_callback(dist, device=None):
     """The same exchange step over a caller-supplied all-gather (here: torch.distributed, e.g. gloo): for tests on a one-GPU
-    box, where RCCL refuses two ranks on one device."""
+    box, where RCCL refuses two ranks on one device.  device: stage the buffers on that device (needed when the process group's
+    backend is nccl, which does not take host tensors)."""
     import torch
     lib = load_library()
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -211,9 +224,11 @@ def dist_init_callback(dist):
     def gather(send, recv, count, ctx):
         try:
             a = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)).copy())
+            if device is not None:
+                a = a.to(device)
             out = [torch.empty_like(a) for _ in range(world)]
             dist.all_gather(out, a)
-            np.ctypeslib.as_array(recv, shape=(count * world,))[:] = torch.cat(out).numpy()
+            np.ctypeslib.as_array(recv, shape=(count * world,))[:] = torch.cat(out).cpu().numpy()
             return 0
         except Exception:
             return 1
