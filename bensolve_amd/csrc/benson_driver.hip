@@ -186,7 +186,7 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
                 pool_slots = (int)fit;
                 h->batch_cap = std::max(1, (pool_slots - 4) / 4);       // (only where memory cut the pool: callers that sized it themselves keep their batch)
             }
-        }
+        } else (void)hipGetLastError();                                  // (no figure, no cut; the error must not surface at the next launch check)
     }
     int rc = bslv_lpq_create(&h->lp, M, N, L.data(), lo.data(), up.data(), cost.data(), m + q, r, pool_slots);
     if (rc) { bslv_benson_destroy(h); return rc; }
