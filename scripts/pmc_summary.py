@@ -18,7 +18,11 @@ def per_kernel(path, counter):
 F = per_kernel(sys.argv[1], "FETCH_SIZE")
 W = per_kernel(sys.argv[2], "WRITE_SIZE")
 pivots = passes = 0
+dims = None
 for line in open(sys.argv[3]):
+    md = re.search(r"LP (\d+) x (\d+)", line)
+    if md:
+        dims = (int(md.group(1)), int(md.group(2)))
     m = re.search(r"pivots \[(\d+)\] passes (\d+)", line)
     if m:
         pivots += int(m.group(1)); passes += int(m.group(2))
@@ -32,7 +36,10 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- pytho
 ku = "bslv::k_flush"
 rd = 2.0 * F[ku][0] * 1024 / passes
 wr = W[ku][0] * 1024 / passes
-alg = 16.0 * (1000 + 5 + 1) * (500 + 2)
+alg = 16.0 * (dims[0] + 1) * dims[1] if dims and len(sys.argv) > 4 else 16.0 * (1000 + 5 + 1) * (500 + 2)      # one read + one write of the (M + 1) x N tableau
+if len(sys.argv) > 4:
+    out["command"] = out["command"].replace("S-mid 256", sys.argv[4])
+    out["workload"] = "%s: P2 LPs %d x %d (scripts/lp_probe.py); pass and pivot counts from the probe's own report" % (sys.argv[4], dims[0], dims[1])
 out["k_flush"] = {"tableau_passes_in_run": passes, "pivots_in_run": pivots, "pivots_per_pass": round(pivots / passes, 2),
                   "read_bytes_per_pass_corrected": round(rd), "write_bytes_per_pass": round(wr),
                   "traffic_bytes_per_pass": round(rd + wr), "algorithmic_bytes_per_pass": round(alg), "traffic_over_algorithmic": round((rd + wr) / alg, 4),
