@@ -25,6 +25,8 @@ static void usage(void)
            "  -o, --output_filename F  base name of the result files (default: input name up to the first '.')\n"
            "  -m, --message_level N    0-3 (default 1)\n"
            "  -B, --batch N            LPs per outer iteration (default 1024)\n"
+           "  -k/-L/-l METHOD, -M N, -f FORMAT, -p, -t   accepted as in the reference's command line; the LP method is recorded in the\n"
+           "                           .log (every LP is solved by the engine's dual simplex), no graphics file is written\n"
            );
 }
 
@@ -85,7 +87,8 @@ int main(int argc, char **argv)
 {
     if (argc < 2 || argv[1][0] == '-') { usage(); return 1; }
     const char *file = argv[1];
-    int bounded = 0, msg = 1, batch = 1024, dual2 = 0, dual1 = 0, presol = 0;
+    int bounded = 0, msg = 1, batch = 1024, dual2 = 0, dual1 = 0, presol = 0, plot_asked = 0;
+    int lp_method[3] = {0, 0, 0};                  /* per phase: 0 as the reference's default, 1 primal_simplex, 2 dual_simplex, 3 dual_primal_simplex */
     double eps = 1e-7, eps1 = 1e-7;
     char base[1024] = "";
     for (int a = 2; a < argc; a++) {
@@ -106,6 +109,23 @@ int main(int argc, char **argv)
             if (!strcmp(v1, "dual")) dual1 = 1; else if (!strcmp(v1, "primal")) dual1 = 0; else { printf("option --alg_phase1 (-A): invalid argument\n"); return 1; }
         }
         else if (!strcmp(o, "-E") || !strcmp(o, "--eps_phase1")) { eps1 = atof(ARG()); if (!(eps1 > 0)) { printf("option --eps_phase1 (-E): invalid argument\n"); return 1; } }
+        /* options of the reference's command line that change nothing here: accepted with the reference's own argument check
+         * (bslv_main.c:112-170), so that a documented command line such as ex/example09.m's
+         * "ex09.vlp -e 1e-2 -m 3 -L primal_simplex -l primal_simplex -p" runs as it stands.  The LP method is recorded in the .log;
+         * every LP is solved by the engine's dual simplex; no graphics file is written. */
+        else if (!strcmp(o, "-k") || !strcmp(o, "--lp_method_phase0") || !strcmp(o, "-L") || !strcmp(o, "--lp_method_phase1") || !strcmp(o, "-l") || !strcmp(o, "--lp_method_phase2")) {
+            const int ph = (!strcmp(o, "-k") || !strcmp(o, "--lp_method_phase0")) ? 0 : (!strcmp(o, "-L") || !strcmp(o, "--lp_method_phase1")) ? 1 : 2;
+            const char *v = ARG();
+            if (!strcmp(v, "primal_simplex")) lp_method[ph] = 1;
+            else if (!strcmp(v, "dual_simplex")) lp_method[ph] = 2;
+            else if (!strcmp(v, "dual_primal_simplex")) lp_method[ph] = 3;
+            else if (ph > 0 && !strcmp(v, "auto")) lp_method[ph] = 0;
+            else { printf("option --lp_method_phase%d (-%c): invalid argument\n", ph, ph == 0 ? 'k' : ph == 1 ? 'L' : 'l'); return 1; }
+        }
+        else if (!strcmp(o, "-M") || !strcmp(o, "--lp_message_level")) { const int v = atoi(ARG()); if (v < 0 || v > 3) { printf("option --lp_message_level (-M): invalid argument\n"); return 1; } }
+        else if (!strcmp(o, "-f") || !strcmp(o, "--format")) { const char *v = ARG(); if (strcmp(v, "auto") && strcmp(v, "long") && strcmp(v, "short")) { printf("option --format (-f): invalid argument\n"); return 1; } }
+        else if (!strcmp(o, "-p") || !strcmp(o, "--plot")) plot_asked = 1;
+        else if (!strcmp(o, "-t") || !strcmp(o, "--test")) { /* the reference's integrity tests of its own polytope lists: nothing to test here */ }
         else if (!strcmp(o, "-h") || !strcmp(o, "--help")) { usage(); return 1; }
         else { printf("invalid option %s\n", o); return 1; }
     }
@@ -126,6 +146,7 @@ int main(int argc, char **argv)
 
     bslv_vlp *v = NULL;
     int line = 0;
+    if (plot_asked && msg >= 1) printf("option --plot (-p): graphics files are not written by this driver\n");
     if (msg >= 1) printf("loading ... \n");
     if (bslv_vlp_read(file, &v, &line)) {
         printf("Error while reading %s: line %d: %s\n", file, line, bslv_vlp_message(v));
@@ -179,9 +200,15 @@ int main(int argc, char **argv)
         fprintf(lf, "  bounded:            %s\n", bounded ? "yes (run phase 2 only)" : "no (run phases 0 to 2)");
         fprintf(lf, "  solution:           %s\n", presol ? "on (solutions (pre-image) written to files)" : "off (no solution output)");
         fprintf(lf, "  format:             %s\n", "long");
-        fprintf(lf, "  lp_method_phase0:   %s\n", "dual_primal_simplex (dual simplex, if not succesful, primal simplex)");
-        fprintf(lf, "  lp_method_phase1:   %s\n", "dual_primal_simplex (dual simplex, if not succesful, primal simplex)");
-        fprintf(lf, "  lp_method_phase2:   %s\n", dual2 ? "primal_simplex" : "dual_primal_simplex (dual simplex, if not succesful, primal simplex)");
+        {
+            static const char *const mname[4] = {NULL, "primal_simplex", "dual_simplex", "dual_primal_simplex (dual simplex, if not succesful, primal simplex)"};
+            const char *m0 = lp_method[0] ? mname[lp_method[0]] : mname[3];
+            const char *m1 = lp_method[1] ? mname[lp_method[1]] : mname[3];
+            const char *m2 = lp_method[2] ? mname[lp_method[2]] : (dual2 ? mname[1] : mname[3]);
+            fprintf(lf, "  lp_method_phase0:   %s\n", m0);
+            fprintf(lf, "  lp_method_phase1:   %s\n", m1);
+            fprintf(lf, "  lp_method_phase2:   %s\n", m2);
+        }
         fprintf(lf, "  message_level:      %d\n", msg);
         fprintf(lf, "  lp_message_level:   %d\n", 0);
         fprintf(lf, "  alg_phase1:         %s\n", dual1 ? "dual" : "primal");

@@ -193,3 +193,21 @@ def test_cli_ex09_is_certified(tmp_path):
     1.36 GB; the pool is cut to what fits into the free device memory and the extended selection is on from the first LP."""
     cert = _certified_run(tmp_path, "ex09", 1e-2, 1500)
     assert cert["points"] >= 10 and cert["dual_cone_generators"] == 6
+
+
+def test_cli_accepts_the_reference_command_line(tmp_path):
+    """The options of the reference's command line that change nothing here (-k / -L / -l METHOD, -M, -f, -p, -t; bslv_main.c:112-170)
+    are accepted with the reference's own argument check, so that a documented command such as ex/example09.m's
+    '-e 1e-2 -m 3 -L primal_simplex -l primal_simplex -p' runs as it stands; the method is recorded in the .log."""
+    vlp = os.path.join(ROOT, "tests", "golden", "ex", "ex01.vlp")
+    base = os.path.join(tmp_path, "ex01")
+    r = subprocess.run([CLI, vlp, "-e", "1e-2", "-m", "3", "-L", "primal_simplex", "-l", "primal_simplex", "-k", "dual_simplex", "-M", "0", "-f", "long", "-p", "-t", "-o", base],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    log = open(base + ".log").read()
+    assert "lp_method_phase0:   dual_simplex" in log and "lp_method_phase1:   primal_simplex" in log and "lp_method_phase2:   primal_simplex" in log
+    assert "graphics files are not written" in r.stdout
+    bad = subprocess.run([CLI, vlp, "-l", "simplex"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "option --lp_method_phase2 (-l): invalid argument" in bad.stdout
+    bad = subprocess.run([CLI, vlp, "-k", "auto"], capture_output=True, text=True, timeout=60)          # (phase 0 has no 'auto', bslv_main.c:131-139)
+    assert bad.returncode == 1 and "option --lp_method_phase0 (-k): invalid argument" in bad.stdout
