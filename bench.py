@@ -32,8 +32,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed outer iterations (default 8; S-degenerate: 3, its polyhedron outgrows 32-bit indices after ~6)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed outer iterations before them (default 2; S-degenerate: 0)")
+    ap.add_argument("--steps", type=int, default=None, help="timed outer iterations (default 20; S-degenerate: 3, its polyhedron outgrows 32-bit indices after ~6)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed outer iterations before them (default 4; S-degenerate: 0)")
     ap.add_argument("--workload", default="S-mid")
     ap.add_argument("--batch", type=int, default=0, help="LPs per GPU per step (default by workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,9 +85,9 @@ def main():
         transport = dist_init_rccl(dist, device)
 
     if args.steps is None:
-        args.steps = 3 if args.workload == "S-degenerate" else 8
+        args.steps = 3 if args.workload == "S-degenerate" else 20     # (the rate moves with the window: waves of redundant LPs -- 5-step windows gave 62 k .. 108 k LPs/s on S-mid; 20 steps average over them)
     if args.warmup is None:
-        args.warmup = 0 if args.workload == "S-degenerate" else 2
+        args.warmup = 0 if args.workload == "S-degenerate" else 4
     defaults = {"S-small": 2048, "S-mid": 2048, "S-degenerate": 64}
     B = args.batch or defaults.get(args.workload, 256)
     # CPU sample: (warm-up, rated) LPs in the reference's vertex order, then newest first
