@@ -233,6 +233,7 @@ def main():
                      "passes_over_polyhedron": passes_poly, "cuts_per_pass": round(cuts / max(passes_poly, 1), 2),
                      "single_cut_pipeline_cuts": ps["single_cuts"] - ps0["single_cuts"], "hot_chunks": ps["hot_chunks"] - ps0["hot_chunks"],
                      "pair_tests_per_sec": round(pair_tests / dt, 1), "reference_pair_tests_per_sec_1core": 6.9e6,
+                     "mailbox": eng.poly_call("rounds2_health"),
                      "note": "a single cut runs on ~10^2 workgroups for ~50 us (dependent chain of 3 launches); a multi-cut pass applies all independent cuts of a batch in one sweep"}
 
     cpu = None

@@ -2475,7 +2475,7 @@ struct bslv_poly {
     int chunk_cuts = 512;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
     int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
     int r2_min_cuts = 0;              // rounds go on while they hold at least this many cuts on average (debug_set key 8; 0: until the rounds hold one cut each; -1: always)
-    long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0, r2_late_left = 0;
+    long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0, r2_late_left = 0, r2_torn_reads = 0;
     int batch_mode = 1;               // 0: one cut at a time, 1: rounds of independent cuts
     long rounds_run = 0, conf_pairs = 0, conf_cuts = 0;
     int dense_streak = 0, dense_skip = 0;   // adaptive skipping of the conflict pass (apply_cuts_rounds)
@@ -3638,6 +3638,7 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
 }
 long bslv_poly_sharded_prunes(const bslv_poly *h) { return h ? h->n_sharded : 0; }
 long bslv_poly_rounds2_late_left(const bslv_poly *h) { return h ? h->r2_late_left : 0; }
+long bslv_poly_rounds2_torn_reads(const bslv_poly *h) { return h ? h->r2_torn_reads : 0; }
 int bslv_poly_path_stats(const bslv_poly *h, long out[6])
 {
     if (!h || !out) return BSLV_E_ARG;

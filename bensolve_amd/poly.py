@@ -104,6 +104,13 @@ class PolyEngine:
         check(self.lib.bslv_poly_rounds2_stats(self.h, out))
         return dict(rounds=out[0], cuts=out[1], chunks=out[2], fallback_prunes=out[3], declined=out[4])
 
+    def rounds2_health(self):
+        """(cuts handed back late, mailbox reads repeated because the sequence number arrived before the state)"""
+        for f in ("bslv_poly_rounds2_late_left", "bslv_poly_rounds2_torn_reads"):
+            getattr(self.lib, f).restype = ctypes.c_long
+            getattr(self.lib, f).argtypes = [ctypes.c_void_p]
+        return dict(late_left=self.lib.bslv_poly_rounds2_late_left(self.h), torn_reads=self.lib.bslv_poly_rounds2_torn_reads(self.h))
+
     def sharded_prunes(self):
         """multi-GPU: adjacency prunes whose pair space was dealt to the ranks"""
         self.lib.bslv_poly_sharded_prunes.restype = ctypes.c_long

@@ -148,6 +148,9 @@ long bslv_poly_sharded_prunes(const bslv_poly *h);
 /* cuts that were still untouched when a chunk's rounds ended on "no cut alive" and were handed to the one-cut pipeline instead
  * (0 in every run but one of round 2's test runs; kept as a counter so that it cannot hide) */
 long bslv_poly_rounds2_late_left(const bslv_poly *h);
+/* reads of a round's mailbox (mapped pinned memory, four cache lines) whose sequence number had arrived before the rest of the
+ * state: detected by the checksum the state carries and repeated */
+long bslv_poly_rounds2_torn_reads(const bslv_poly *h);
 /* test hook, same switches as the BSLV_* environment variables but at run time: key 0 dynamic LDS bytes of the one-workgroup
  * prune (64 forces the multi-kernel prune), 1 speculative launch on/off, 2 hot mode on/off, 3 CROSS_UB, 4 size of a new facet
  * from which the multi-kernel prune builds facet-major member lists (default 4096), 5 member lists on/off, 6 device-selected
