@@ -102,7 +102,9 @@ __device__ __forceinline__ Tri block_sum(Tri v, Tri *lds /* >= 16 */)
 // scan of per-block sums by one workgroup; sums[] becomes exclusive prefixes, totals[0] the grand total
 // host mailbox in mapped pinned memory: the scan tail publishes totals (and the classify counters)
 // straight to the host, which spins on `seq` instead of paying a stream synchronise per readback
-struct Mail { volatile int seq; int cnt[4]; Tri t; Tri k2t; int k2seq; };    // k2t/k2seq: result of the prune that was in flight, forwarded by round A
+// One mailbox = ONE 64-byte line of mapped pinned memory (48 bytes of payload): the fields are stored, a system fence, then seq.
+// (A state spanning several lines was once read with the new seq and the old content: poly_rounds2_kernels.inc, RState.)
+struct alignas(64) Mail { volatile int seq; int cnt[4]; Tri t; Tri k2t; int k2seq; };    // k2t/k2seq: result of the prune that was in flight, forwarded by round A
 __global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *totals, Mail *mail = nullptr, const int *counters = nullptr, int seq = 0)
 {
     __shared__ Tri lds[16];
