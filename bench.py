@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--policy", type=int, default=0, help="batch selection: 1 newest first, 2 spread, 3 newest first with at most --sib-cap children of one cut (default by workload)")
     ap.add_argument("--sib-cap", type=int, default=1)
     ap.add_argument("--sib-window", type=int, default=8)
+    ap.add_argument("--fronts", type=int, default=8, help="policy 4: number of depth-first fronts")
     ap.add_argument("--pool", type=int, default=0, help="tableau slots (default 4*batch+64)")
     ap.add_argument("--no-pair", action="store_true", help="skip the S-small whole-run GPU/CPU pair of cpu_baseline")
     ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
@@ -104,6 +105,8 @@ def main():
         eng.set_policy(args.policy)
         if args.policy == 3:
             eng.set_sibling_rule(args.sib_cap, args.sib_window)
+        if args.policy == 4:
+            eng.set_fronts(args.fronts, args.sib_cap)
     st = eng.start()
     if st != 0:
         raise SystemExit("phase 2 start failed: vlp status %d" % st)

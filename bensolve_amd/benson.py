@@ -108,6 +108,10 @@ class BensonEngine:
         self.lib.bslv_benson_set_sibling_rule.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         check(self.lib.bslv_benson_set_sibling_rule(self.h, int(cap), int(window)))
 
+    def set_fronts(self, nfronts, sib_cap=1 << 20):
+        self.lib.bslv_benson_set_fronts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        check(self.lib.bslv_benson_set_fronts(self.h, int(nfronts), int(sib_cap)))
+
     def pool_stats(self):
         out = (ctypes.c_long * 4)()
         self.lib.bslv_benson_pool_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -48,11 +48,16 @@ struct bslv_benson {
     std::deque<std::pair<int, int>> parents;          // (facet, slot) in creation order
     std::unordered_map<int, int> facet_slot;
     std::vector<int> facet_owner;                     // by facet id: rank that solved its LP (-1 unknown)
+    // policy 4: K depth-first fronts.  A vertex belongs to the front of the cut that created it; a cut to the front of the
+    // vertex whose LP returned it.  A front that runs dry is re-seeded with the older half of the richest front's facets.
+    std::vector<int> facet_front;                     // by facet id (missing / -1: front 0)
+    int nfronts = 8;
+    long front_splits = 0;
     bool started = false;
     // batch contexts (after collect).  Two of them so that the LPs of batch k can run (on the LP engine's
     // stream, from a second host thread) while the cuts of batch k-1 are applied (polyhedron engine)
     struct BatchCtx {
-        std::vector<int> b_idx, b_parent, b_owner;    // whole batch (all ranks)
+        std::vector<int> b_idx, b_parent, b_owner, b_front;    // whole batch (all ranks)
         std::vector<double> b_val;
         std::vector<int> l_pos, l_slot;               // local shard: position in batch, dst slot
     } ctx[2];
@@ -65,6 +70,7 @@ struct bslv_benson {
     std::vector<double> slot_src;                     // per slot: vertex its LP was solved for (pool_slots x q)
     std::vector<char> slot_valid;
     std::vector<int> slot_gen;                        // generations of warm starts between the root tableau and this slot
+    std::vector<int> last_src, last_piv, last_gen;    // per LP of the last solve_local (tuning: bslv_benson_last_local)
     // totals
     long tot_lps = 0, tot_cuts = 0, tot_pivots = 0;
 };
@@ -260,6 +266,7 @@ int bslv_benson_start(bslv_benson *h, int *vlp_status)
 // Select the next batch (the newest max_batch unprocessed elements; directions are only marked,
 // bslv_algs.c:1036-1040) and deal it to ranks.  n_local = LPs this rank will solve.
 int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, int world, int *n_local, int *n_total);
+static int deal_batch(bslv_benson *h, bslv_benson::BatchCtx &B, int rank, int world, int *n_local, int *n_total);
 int bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int *n_local, int *n_total)
 {
     return bslv_benson_collect_ctx(h, 0, max_batch, rank, world, n_local, n_total);
@@ -276,19 +283,79 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
     max_batch = (int)std::min<long long>(max_batch, (long long)h->batch_cap * world);          // (what the pool of tableaux can serve, see bslv_benson_create_ex)
     int rc, cnt = 0;
     for (;;) {
-        const int pol = h->policy == 3 ? 1 : h->policy;
+        const int pol = h->policy >= 3 ? 1 : h->policy;
         if ((rc = bslv_poly_unprocessed2(h->poly, 0, pol, nullptr, nullptr, nullptr, nullptr, &cnt))) return rc;
         // policy 3 looks at a window of the newest unprocessed elements several batches deep and takes at most `sib_cap`
         // children of one cut from it (see bslv_benson_set_policy)
-        const long long want = h->policy == 3 ? (long long)max_batch * h->sib_window : max_batch;
+        const long long want = h->policy == 4 ? (1LL << 30) : h->policy == 3 ? (long long)max_batch * h->sib_window : max_batch;
         int nb = (int)std::min<long long>(cnt, want);
         std::vector<int> idx(nb), ideal(nb), parent(nb);
         std::vector<double> val((size_t)nb * q);
         if (nb && (rc = bslv_poly_unprocessed2(h->poly, nb, pol, idx.data(), val.data(), ideal.data(), parent.data(), &cnt))) return rc;
         std::vector<int> dirs;
-        B.b_idx.clear(); B.b_val.clear(); B.b_parent.clear();
+        B.b_idx.clear(); B.b_val.clear(); B.b_parent.clear(); B.b_front.clear();
         int taken = 0;
-        if (h->policy == 3) {
+        if (h->policy == 4) {
+            // K fronts, newest first inside each (at most sib_cap children of one cut per front and batch)
+            const int K = std::max(1, h->nfronts);
+            auto front_of = [&](int f) { return (f >= 0 && f < (int)h->facet_front.size() && h->facet_front[f] >= 0) ? h->facet_front[f] % K : 0; };
+            std::vector<std::vector<int>> byf(K);                       // positions in the window, ascending slot order
+            for (int k = 0; k < nb; k++) {
+                if (ideal[k]) { dirs.push_back(idx[k]); taken++; continue; }
+                byf[front_of(parent[k])].push_back(k);
+            }
+            const int quota = std::max(1, max_batch / K);
+            // re-seed fronts that cannot fill their quota from the richest front: the facets of its older half move over
+            for (int guard = 0; guard < 4 * K; guard++) {
+                int poor = -1, rich = 0;
+                for (int f = 0; f < K; f++) { if ((int)byf[f].size() < quota && (poor < 0 || byf[f].size() < byf[poor].size())) poor = f; if (byf[f].size() > byf[rich].size()) rich = f; }
+                if (poor < 0 || (int)byf[rich].size() < 4 * quota || !byf[poor].empty()) break;
+                const int half = (int)byf[rich].size() / 2;
+                const int fsplit = parent[byf[rich][half]];              // facets below this id (older cuts) change front
+                if ((int)h->facet_front.size() < bslv_poly_ndual(h->poly)) h->facet_front.resize(bslv_poly_ndual(h->poly), -1);
+                std::vector<int> stay;
+                for (int k : byf[rich]) {
+                    const int f = parent[k];
+                    if (f >= 0 && f < fsplit) { h->facet_front[f] = poor; byf[poor].push_back(k); } else stay.push_back(k);
+                }
+                if (byf[poor].empty()) break;
+                byf[rich].swap(stay);
+                h->front_splits++;
+            }
+            std::vector<int> pick;
+            std::vector<int> want(K, quota);
+            int spare = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                for (int f = 0; f < K; f++) {
+                    if (pass == 1) { if (spare <= 0) break; want[f] = spare; }
+                    std::unordered_map<int, int> per_parent;
+                    int got = 0;
+                    std::vector<int> &L = byf[f];
+                    std::vector<int> rest;
+                    for (int t = (int)L.size() - 1; t >= 0; t--) {
+                        const int k = L[t];
+                        if (got >= want[f] || (parent[k] >= 0 && ++per_parent[parent[k]] > h->sib_cap)) { rest.push_back(k); continue; }
+                        pick.push_back(k); B.b_front.push_back(f); got++;
+                    }
+                    std::reverse(rest.begin(), rest.end());
+                    L.swap(rest);
+                    if (pass == 0) spare += want[f] - got; else spare -= got;
+                }
+            }
+            std::vector<int> ord(pick.size());
+            for (size_t t = 0; t < ord.size(); t++) ord[t] = (int)t;
+            std::sort(ord.begin(), ord.end(), [&](int a, int b) { return pick[a] < pick[b]; });
+            std::vector<int> fr2;
+            for (int t : ord) {
+                const int k = pick[t];
+                B.b_idx.push_back(idx[k]);
+                B.b_parent.push_back(parent[k]);
+                fr2.push_back(B.b_front[t]);
+                B.b_val.insert(B.b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
+            }
+            B.b_front.swap(fr2);
+            taken += (int)pick.size();
+        } else if (h->policy == 3) {
             // newest first; the chosen elements are handed on in ascending slot order, as with the other policies
             std::unordered_map<int, int> per_parent;
             std::vector<int> pick;
@@ -318,6 +385,12 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
         h->unprocessed_left = cnt - taken;
         if (!B.b_idx.empty() || dirs.empty()) break;     // only directions in this window: look again
     }
+    return deal_batch(h, B, rank, world, n_local, n_total);
+}
+// the batch is chosen (B.b_idx, b_val, b_parent): deal it to the ranks
+static int deal_batch(bslv_benson *h, bslv_benson::BatchCtx &B, int rank, int world, int *n_local, int *n_total)
+{
+    int rc;
     const int nb = (int)B.b_idx.size();
     // pipelined mode: the batch is 'being processed' from now on, so the next collect skips it (a vertex that gets a
     // cut is removed by that cut; one that does not is confirmed -- either way the mark is final)
@@ -338,6 +411,30 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
     *n_local = (int)B.l_pos.size();
     *n_total = nb;
     return 0;
+}
+
+// Tuning hook: the caller chooses the batch itself (elements idx[] with their coordinates and parent facets, as
+// bslv_poly_unprocessed2 returns them); directions among them must have been marked by the caller.
+int bslv_benson_collect_given(bslv_benson *h, int n, const int *idx, const double *val, const int *parent, int rank, int world, int *n_local, int *n_total)
+{
+    if (!h || !h->started || n < 0 || world < 1 || rank < 0 || rank >= world || !n_local || !n_total || (n && (!idx || !val || !parent))) {
+        set_error("bslv_benson_collect_given: bad argument / not started");
+        return BSLV_E_ARG;
+    }
+    bslv_benson::BatchCtx &B = h->ctx[0];
+    h->rank = rank; h->world = world;
+    B.b_idx.assign(idx, idx + n);
+    B.b_parent.assign(parent, parent + n);
+    B.b_val.assign(val, val + (size_t)n * h->q);
+    return deal_batch(h, B, rank, world, n_local, n_total);
+}
+// per LP of the last solve_local of this rank: warm-start slot (0 = root tableau), pivots, generation of the new slot
+int bslv_benson_last_local(bslv_benson *h, int max_out, int *src, int *pivots, int *gen)
+{
+    if (!h) return BSLV_E_ARG;
+    const int n = (int)std::min<size_t>(h->last_src.size(), (size_t)std::max(max_out, 0));
+    for (int k = 0; k < n; k++) { if (src) src[k] = h->last_src[k]; if (pivots) pivots[k] = h->last_piv[k]; if (gen) gen[k] = h->last_gen[k]; }
+    return n;
 }
 
 static int gen_max()      // BSLV_GEN_MAX: test hook
@@ -477,6 +574,8 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
             redo.swap(still);
         }
     }
+    h->last_src = src; h->last_piv = it; h->last_gen.resize(nl);
+    for (int k = 0; k < nl; k++) h->last_gen[k] = h->slot_gen[dst[k]];
     std::vector<double> ww((size_t)nl * q), yy((size_t)nl * q), zz(nl);
     if ((rc = bslv_lpq_get_dual(h->lp, nl, dst.data(), h->m, q, ww.data()))) return rc;                 // bslv_algs.c:1050
     if ((rc = bslv_lpq_get_primal(h->lp, nl, dst.data(), h->M + h->n, q, yy.data()))) return rc;        // :1055
@@ -572,6 +671,11 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     // bookkeeping: facet ids f0.. were assigned in this order on every rank
     std::lock_guard<std::mutex> lk(h->slot_mu);
     h->facet_owner.resize(f0 + ncut, -1);
+    std::unordered_map<int, int> front_of_src;
+    if (h->policy == 4) {
+        h->facet_front.resize(f0 + ncut, -1);
+        for (size_t k = 0; k < B.b_idx.size() && k < B.b_front.size(); k++) front_of_src[B.b_idx[k]] = B.b_front[k];
+    }
     long applied = 0;
     // local slot of a record: position in this rank's shard
     std::unordered_map<int, int> slot_of_src;
@@ -580,6 +684,10 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
         const double *rec = records + (size_t)cut_src[c] * RL;
         const int owner = (int)rec[4 + q], f = f0 + c;
         h->facet_owner[f] = owner;
+        if (h->policy == 4) {
+            auto it = front_of_src.find((int)rec[0]);
+            h->facet_front[f] = it != front_of_src.end() ? it->second : 0;
+        }
         if (prc[c] == 0) applied++;
         if (owner == h->rank) {
             auto it = slot_of_src.find((int)rec[0]);
@@ -636,8 +744,14 @@ int bslv_benson_set_pipelined(bslv_benson *h, int on)
 }
 int bslv_benson_set_policy(bslv_benson *h, int policy)
 {
-    if (!h || policy < 1 || policy > 3) return BSLV_E_ARG;
+    if (!h || policy < 1 || policy > 4) return BSLV_E_ARG;
     h->policy = policy;
+    return 0;
+}
+int bslv_benson_set_fronts(bslv_benson *h, int nfronts, int sib_cap)
+{
+    if (!h || nfronts < 1 || nfronts > 1024 || sib_cap < 1) return BSLV_E_ARG;
+    h->nfronts = nfronts; h->sib_cap = sib_cap;
     return 0;
 }
 int bslv_benson_set_sibling_rule(bslv_benson *h, int cap, int window)

@@ -2474,7 +2474,8 @@ struct bslv_poly {
     RoundsBuf *rounds = nullptr;      // scratch of the multi-cut path
     Rounds2Buf *rounds2 = nullptr;    // scratch of the device-selected rounds inside a hot chunk (poly_rounds2_host.inc)
     bool rounds2_enabled = true;      // BSLV_NO_ROUNDS2=1 / bslv_poly_debug_set(h, 6, 0): hot chunks go through the single-cut pipeline
-    int chunk_cuts = 512;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
+    bool r2_mis = true;               // rounds take a maximal independent set from the chunk's conflict matrix (BSLV_R2_MIS=0 / debug_set key 11: local minima of one order, round 2)
+    int chunk_cuts = 1024;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
     int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
     int r2_min_cuts = 0;              // rounds go on while they hold at least this many cuts on average (debug_set key 8; 0: until the rounds hold one cut each; -1: always)
     long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0, r2_late_left = 0, r2_torn_reads = 0;
@@ -3287,6 +3288,8 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (getenv("BSLV_NO_SPEC")) h->speculate = false;
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
     if (getenv("BSLV_NO_ROUNDS2")) h->rounds2_enabled = false;
+    if (const char *e = getenv("BSLV_R2_MIS")) h->r2_mis = atoi(e) != 0;
+    if (!h->r2_mis) h->chunk_cuts = 512;
     if (const char *e = getenv("BSLV_CHUNK_CUTS")) h->chunk_cuts = std::min(4096, std::max(32, atoi(e)));
     if (const char *e = getenv("BSLV_R2_MIN_CUTS")) h->r2_min_cuts = std::max(-1, atoi(e));
     if (const char *e = getenv("BSLV_R2_RULE")) h->r2_rule = atoi(e) ? 1 : 0;
@@ -3632,6 +3635,7 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 6: h->rounds2_enabled = value != 0; return 0;                  /* device-selected rounds of independent cuts inside a hot chunk */
     case 7: h->chunk_cuts = (int)std::min(4096L, std::max(32L, value)); return 0;    /* cuts classified and applied together */
     case 10: h->shard_min = (int)std::max(2L, value); return 0;           /* multi-GPU: facets from this size on have their pair space dealt to the ranks */
+    case 11: h->r2_mis = value != 0; return 0;                            /* rounds: maximal independent set from the conflict matrix (1) / local minima of one order (0) */
     case 9: g_k1_mfma = value != 0; return 0;                            /* incidence kernel K1 on the matrix pipe from 16 halfspaces on (1) or the scalar kernel (0, default); process-wide */
     case 8: h->r2_min_cuts = (int)std::max(-1L, value); return 0;        /* rounds go on while they average at least this many cuts (0: until every round holds one cut, -1: always) */
     case 5: h->member_lists = value != 0; return 0;                     /* edges of large facets confirmed through member lists (1) or against all elements (0) */           /* facets from this size on confirm edges through the facet-major member lists (4096) */

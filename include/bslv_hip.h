@@ -244,6 +244,14 @@ int  bslv_benson_unprocessed_left(const bslv_benson *h);
  * sequential loop never solves them, because the first copy of the cut removes the siblings (bslv_algs.c:1030-1080) */
 int  bslv_benson_set_policy(bslv_benson *h, int policy);
 int  bslv_benson_set_sibling_rule(bslv_benson *h, int cap, int window);
+/* policy 4: K depth-first fronts (a vertex belongs to the front of the cut that created it, a cut to the front of the vertex
+ * whose LP returned it; newest first inside a front, at most sib_cap children of one cut per front and batch) */
+int  bslv_benson_set_fronts(bslv_benson *h, int nfronts, int sib_cap);
+/* tuning hooks (no counterpart in the reference): the caller chooses the batch itself -- elements with their coordinates and
+ * parent facets as bslv_poly_unprocessed2 returns them -- and reads, per LP of this rank's last solve_local, the warm-start slot
+ * (0 = root tableau), the pivots and the generation of the new slot; returns the number of entries written */
+int  bslv_benson_collect_given(bslv_benson *h, int n, const int *idx, const double *val, const int *parent, int rank, int world, int *n_local, int *n_total);
+int  bslv_benson_last_local(bslv_benson *h, int max_out, int *src, int *pivots, int *gen);
 /* tableau pool: out[0] free slots, [1] resident warm-start sources, [2] held by a batch in flight, [3] pool size */
 int  bslv_benson_pool_stats(bslv_benson *h, long out[4]);
 int  bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots);

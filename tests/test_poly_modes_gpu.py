@@ -13,7 +13,7 @@ from test_poly_gpu import assert_slotwise_equal
 
 pytestmark = pytest.mark.gpu
 
-HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS"]
+HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS", "BSLV_R2_MIS"]
 MODES = {
     "default": {},
     "no_spec": {"BSLV_NO_SPEC": "1"},
@@ -130,6 +130,7 @@ R2_MODES = {
     "rounds, small chunks": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_CHUNK_CUTS": "64"},
     "rounds, every prune through the multi-kernel path": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_K2_LDS": "64"},
     "rounds without speculation in the tail": {"BSLV_NO_SPEC": "1"},
+    "rounds by the local-minima rule of round 2 (no conflict matrix)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "0"},
 }
 
 
