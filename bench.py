@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--sib-cap", type=int, default=1)
     ap.add_argument("--sib-window", type=int, default=8)
     ap.add_argument("--fronts", type=int, default=8, help="policy 4: number of depth-first fronts")
+    ap.add_argument("--fam-mode", type=int, default=2, help="policy 6: parents newest first (0), pseudo-random (1), far apart (2)")
+    ap.add_argument("--fam-batches", type=int, default=2, help="policy 6: parents among the cuts of the last N outer iterations")
     ap.add_argument("--pool", type=int, default=0, help="tableau slots (default 4*batch+64)")
     ap.add_argument("--no-pair", action="store_true", help="skip the S-small whole-run GPU/CPU pair of cpu_baseline")
     ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
@@ -107,6 +109,8 @@ def main():
             eng.set_sibling_rule(args.sib_cap, args.sib_window)
         if args.policy == 4:
             eng.set_fronts(args.fronts, args.sib_cap)
+        if args.policy == 6:
+            eng.set_families(args.fam_mode, args.fam_batches)
     st = eng.start()
     if st != 0:
         raise SystemExit("phase 2 start failed: vlp status %d" % st)

@@ -112,6 +112,10 @@ class BensonEngine:
         self.lib.bslv_benson_set_fronts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         check(self.lib.bslv_benson_set_fronts(self.h, int(nfronts), int(sib_cap)))
 
+    def set_families(self, mode, batches):
+        self.lib.bslv_benson_set_families.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        check(self.lib.bslv_benson_set_families(self.h, int(mode), int(batches)))
+
     def pool_stats(self):
         out = (ctypes.c_long * 4)()
         self.lib.bslv_benson_pool_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -20,6 +20,8 @@
 
 extern "C" {
 int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
+int bslv_poly_children_hist(bslv_poly *h, int first_facet, int n, int *counts, int *total, int *older);
+int bslv_poly_children_of(bslv_poly *h, int nfacets, const int *facets, int max_out, int *idx, double *val, int *ideal, int *parent, int *n_out);
 }
 
 using namespace bslv;
@@ -53,6 +55,13 @@ struct bslv_benson {
     std::vector<int> facet_front;                     // by facet id (missing / -1: front 0)
     int nfronts = 8;
     long front_splits = 0;
+    // policy 6: the batch is made of whole FAMILIES -- all unprocessed children of a cut -- of parents chosen among the cuts of
+    // the last fam_batches outer iterations: fam_mode 0 newest cuts first, 1 pseudo-random, 2 far apart (farthest-point sampling on
+    // the cuts' normals), so that the families of one batch act on different neighbourhoods of the polyhedron
+    int fam_mode = 2, fam_batches = 2;
+    std::deque<int> batch_f0;                         // first dual slot of each of the last outer iterations
+    std::vector<double> facet_normal;                 // q per dual slot (zeros where unknown)
+    long collect_seq = 0;
     bool started = false;
     // batch contexts (after collect).  Two of them so that the LPs of batch k can run (on the LP engine's
     // stream, from a second host thread) while the cuts of batch k-1 are applied (polyhedron engine)
@@ -282,8 +291,72 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
     h->rank = rank; h->world = world;
     max_batch = (int)std::min<long long>(max_batch, (long long)h->batch_cap * world);          // (what the pool of tableaux can serve, see bslv_benson_create_ex)
     int rc, cnt = 0;
+    if (h->policy == 6) {
+        B.b_idx.clear(); B.b_val.clear(); B.b_parent.clear(); B.b_front.clear();
+        const int nf = bslv_poly_ndual(h->poly);
+        h->collect_seq++;
+        int total = 0;
+        // window: the cuts of the last fam_batches outer iterations; widened while it cannot fill the batch
+        int f_lo = h->batch_f0.empty() ? 0 : h->batch_f0[std::max(0, (int)h->batch_f0.size() - h->fam_batches)];
+        std::vector<int> counts, chosen;
+        for (;;) {
+            counts.assign((size_t)std::max(0, nf - f_lo), 0);
+            if ((rc = bslv_poly_children_hist(h->poly, f_lo, (int)counts.size(), counts.data(), &total, nullptr))) return rc;
+            long in_window = 0;
+            for (int c : counts) in_window += c;
+            if (in_window >= max_batch || f_lo == 0) break;
+            f_lo = std::max(0, f_lo - std::max(64, 2 * (nf - f_lo)));
+        }
+        std::vector<int> cand;
+        for (int k = 0; k < (int)counts.size(); k++) if (counts[k] > 0) cand.push_back(f_lo + k);
+        long have = 0;
+        if (h->fam_mode == 2 && (int)h->facet_normal.size() >= nf * q) {
+            // far apart: the first parent is the newest cut, every further one the candidate farthest (in the angle of the normals) from
+            // all parents taken so far
+            std::vector<double> best(cand.size(), 1e300);
+            std::vector<char> used(cand.size(), 0);
+            int cur = cand.empty() ? -1 : (int)cand.size() - 1;
+            while (cur >= 0 && have < max_batch) {
+                used[cur] = 1; chosen.push_back(cand[cur]); have += counts[cand[cur] - f_lo];
+                const double *nc = &h->facet_normal[(size_t)cand[cur] * q];
+                int nxt = -1; double far = -1;
+                for (size_t t = 0; t < cand.size(); t++) {
+                    if (used[t]) continue;
+                    const double *nt = &h->facet_normal[(size_t)cand[t] * q];
+                    double dd = 0;
+                    for (int k = 0; k < q; k++) dd += (nt[k] - nc[k]) * (nt[k] - nc[k]);
+                    if (dd < best[t]) best[t] = dd;
+                    if (best[t] > far) { far = best[t]; nxt = (int)t; }
+                }
+                cur = nxt;
+            }
+        } else {
+            std::vector<int> ord(cand.size());
+            for (size_t t = 0; t < ord.size(); t++) ord[t] = (int)t;
+            if (h->fam_mode == 1) {
+                auto hsh = [&](int f) { unsigned long long z = (unsigned long long)f * 0x9E3779B97F4A7C15ull + (unsigned long long)h->collect_seq * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+                std::sort(ord.begin(), ord.end(), [&](int a, int b) { return hsh(cand[a]) < hsh(cand[b]); });
+            } else std::reverse(ord.begin(), ord.end());
+            for (int t : ord) { if (have >= max_batch) break; chosen.push_back(cand[t]); have += counts[cand[t] - f_lo]; }
+        }
+        std::vector<int> idx(max_batch), ideal(max_batch), parent(max_batch);
+        std::vector<double> val((size_t)max_batch * q);
+        int n = 0;
+        if (!chosen.empty() && (rc = bslv_poly_children_of(h->poly, (int)chosen.size(), chosen.data(), max_batch, idx.data(), val.data(), ideal.data(), parent.data(), &n))) return rc;
+        std::vector<int> dirs;
+        for (int k = 0; k < n; k++) {
+            if (ideal[k]) { dirs.push_back(idx[k]); continue; }
+            B.b_idx.push_back(idx[k]);
+            B.b_parent.push_back(parent[k]);
+            B.b_val.insert(B.b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
+        }
+        if (!dirs.empty() && (rc = bslv_poly_mark(h->poly, (int)dirs.size(), dirs.data()))) return rc;
+        h->unprocessed_left = total - n;
+        // (a window that held only directions: the next call sees them marked)
+        return deal_batch(h, B, rank, world, n_local, n_total);
+    }
     for (;;) {
-        const int pol = h->policy >= 3 ? 1 : h->policy;
+        const int pol = h->policy == 5 ? 3 : h->policy >= 3 ? 1 : h->policy;
         if ((rc = bslv_poly_unprocessed2(h->poly, 0, pol, nullptr, nullptr, nullptr, nullptr, &cnt))) return rc;
         // policy 3 looks at a window of the newest unprocessed elements several batches deep and takes at most `sib_cap`
         // children of one cut from it (see bslv_benson_set_policy)
@@ -671,6 +744,19 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     // bookkeeping: facet ids f0.. were assigned in this order on every rank
     std::lock_guard<std::mutex> lk(h->slot_mu);
     h->facet_owner.resize(f0 + ncut, -1);
+    h->batch_f0.push_back(f0);
+    while (h->batch_f0.size() > 64) h->batch_f0.pop_front();
+    h->facet_normal.resize((size_t)(f0 + ncut) * q, 0.0);
+    for (int c = 0; c < ncut; c++) {                  // normal of the cut y*: (y*_1 .. y*_{q-1}, 1 - c.y*) (lowerV2upperH, bslv_algs.c:287-305), scaled to length 1
+        double *nn = &h->facet_normal[(size_t)(f0 + c) * q];
+        const double *ys = &cuts[(size_t)c * q];
+        double last = 1.0, len = 0;
+        for (int k = 0; k < q - 1; k++) { nn[k] = ys[k]; last -= h->c[k] * ys[k]; }
+        nn[q - 1] = last;
+        for (int k = 0; k < q; k++) len += nn[k] * nn[k];
+        len = std::sqrt(std::max(len, 1e-300));
+        for (int k = 0; k < q; k++) nn[k] /= len;
+    }
     std::unordered_map<int, int> front_of_src;
     if (h->policy == 4) {
         h->facet_front.resize(f0 + ncut, -1);
@@ -744,8 +830,14 @@ int bslv_benson_set_pipelined(bslv_benson *h, int on)
 }
 int bslv_benson_set_policy(bslv_benson *h, int policy)
 {
-    if (!h || policy < 1 || policy > 4) return BSLV_E_ARG;
+    if (!h || policy < 1 || policy > 6) return BSLV_E_ARG;
     h->policy = policy;
+    return 0;
+}
+int bslv_benson_set_families(bslv_benson *h, int mode, int batches)
+{
+    if (!h || mode < 0 || mode > 2 || batches < 1 || batches > 64) return BSLV_E_ARG;
+    h->fam_mode = mode; h->fam_batches = batches;
     return 0;
 }
 int bslv_benson_set_fronts(bslv_benson *h, int nfronts, int sib_cap)

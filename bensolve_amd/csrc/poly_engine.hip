@@ -17,6 +17,9 @@
 #include <chrono>
 #include <algorithm>
 #include <cmath>
+#include <thread>
+#include <atomic>
+#include <cstddef>
 
 namespace bslv {
 
@@ -104,7 +107,46 @@ __device__ __forceinline__ Tri block_sum(Tri v, Tri *lds /* >= 16 */)
 // straight to the host, which spins on `seq` instead of paying a stream synchronise per readback
 // One mailbox = ONE 64-byte line of mapped pinned memory (48 bytes of payload): the fields are stored, a system fence, then seq.
 // (A state spanning several lines was once read with the new seq and the old content: poly_rounds2_kernels.inc, RState.)
-struct alignas(64) Mail { volatile int seq; int cnt[4]; Tri t; Tri k2t; int k2seq; };    // k2t/k2seq: result of the prune that was in flight, forwarded by round A
+struct alignas(64) Mail { volatile int seq; int cnt[4]; Tri t; Tri k2t; int k2seq; unsigned chk, chk2; };    // k2t/k2seq: result of the prune that was in flight, forwarded by round A
+// The fields are stored, a system fence, then seq -- and still the host was once seen to read a new seq with the old content
+// of a mailbox (RState, poly_rounds2_kernels.inc).  So the content carries checksums the reader verifies: chk over (seq, cnt, t),
+// written by every publisher, and chk2 over (k2t, k2seq), which only round A's publisher writes -- left alone, that triple stays
+// the consistent one of an earlier publish, which the reader then simply does not match with the prune it waits for.
+__host__ __device__ __forceinline__ unsigned mail_sum(const int *cnt, const Tri &t, int seq)
+{
+    unsigned c = 0x9E3779B9u;
+    for (int k = 0; k < 4; k++) c = c * 31u + (unsigned)cnt[k];
+    c = c * 31u + (unsigned)t.a; c = c * 31u + (unsigned)t.b; c = c * 31u + (unsigned)t.c;
+    return c + (unsigned)seq * 2654435761u;
+}
+__host__ __device__ __forceinline__ unsigned mail_sum2(const Tri &k2t, int k2seq)
+{
+    unsigned c = 0x85EBCA6Bu;
+    c = c * 31u + (unsigned)k2t.a; c = c * 31u + (unsigned)k2t.b; c = c * 31u + (unsigned)k2t.c;
+    return c * 31u + (unsigned)k2seq;
+}
+// one thread: cnt (4 ints, or nullptr = zeros) and t, then the fence, then seq
+__device__ __forceinline__ void mail_publish(Mail *mail, const int *cnt, const Tri &t, int seq)
+{
+    int c4[4];
+    for (int k = 0; k < 4; k++) { c4[k] = cnt ? cnt[k] : 0; mail->cnt[k] = c4[k]; }
+    mail->t = t;
+    mail->chk = mail_sum(c4, t, seq);
+    __threadfence_system();
+    mail->seq = seq;
+}
+// host: one attempt to take the mailbox content for `seq`.  true: *out is a consistent copy; false: not there yet, or (torn
+// counted) seq was there before its content
+static inline bool mail_try_read(const volatile Mail *m, int seq, Mail *out, long *torn)
+{
+    if (m->seq != seq) return false;
+    __sync_synchronize();
+    Mail c;
+    memcpy((void *)&c, (const void *)m, sizeof c);
+    if (c.seq == seq && c.chk == mail_sum(c.cnt, c.t, seq) && c.chk2 == mail_sum2(c.k2t, c.k2seq)) { *out = c; return true; }
+    if (torn) ++*torn;
+    return false;
+}
 __global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *totals, Mail *mail = nullptr, const int *counters = nullptr, int seq = 0)
 {
     __shared__ Tri lds[16];
@@ -120,12 +162,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(Tri *sums, int nb, Tri *to
     }
     if (threadIdx.x == 0) {
         totals[0] = carry;
-        if (mail) {
-            mail->t = carry;
-            if (counters) for (int k = 0; k < 4; k++) mail->cnt[k] = counters[k];
-            __threadfence_system();
-            mail->seq = seq;
-        }
+        if (mail) mail_publish(mail, counters, carry, seq);
     }
 }
 
@@ -1476,12 +1513,13 @@ __device__ __forceinline__ void publish_round_a(const ScanArgs &A, Tri te)
         c.pad = 0;
         *A.cd = c;
     }
-    A.mail->t = te;
-    if (A.k2src) { A.mail->k2t = A.k2src->t; A.mail->k2seq = A.k2src->seq; }
-    for (int k = 0; k < 3; k++) A.mail->cnt[k] = A.counters[k];
-    A.mail->cnt[3] = ne0;
-    __threadfence_system();
-    A.mail->seq = A.seq;
+    if (A.k2src) {
+        const Tri kt = A.k2src->t;
+        const int ks = A.k2src->seq;
+        A.mail->k2t = kt; A.mail->k2seq = ks; A.mail->chk2 = mail_sum2(kt, ks);
+    }
+    const int c4[4] = {A.counters[0], A.counters[1], A.counters[2], ne0};
+    mail_publish(A.mail, c4, te, A.seq);
 }
 // both scans of round A in one launch
 __global__ __launch_bounds__(1024) void k_scan2(ScanArgs A)
@@ -2210,9 +2248,8 @@ __global__ __launch_bounds__(K2T) void k2_fused_t(PolyView P, int *members, int 
 // at the end of a sequence of cuts this kernel forwards it
 __global__ void k_forward_mail(const Mail *src, Mail *dst)
 {
-    dst->t = src->t;
-    __threadfence_system();
-    dst->seq = src->seq;
+    const Tri t = src->t;
+    mail_publish(dst, nullptr, t, src->seq);
 }
 
 // ---------------- hot mode: set-up and merge (once per chunk of cuts) ----------------
@@ -2346,6 +2383,108 @@ __global__ __launch_bounds__(PB) void k_unproc_emit(PolyView P, int nv, const Tr
     parent[pos] = P.inc_len[i] > 0 ? P.pool[P.inc_off[i] + P.inc_len[i] - 1] : -1;   // newest facet through it
     for (int k = 0; k < P.d; k++) val[(size_t)pos * P.d + k] = P.X[(size_t)k * P.cap + i];
 }
+// "children of the newest cuts first" (bslv_poly_unprocessed2, from_end == 3): the unprocessed elements are ranked by the dual
+// slot of the cut that created them (the newest facet through them), not by their own slot -- slot numbers follow the order in
+// which the cuts of a batch happened to be applied (chunks, the shuffle of the rounds), facet ids the order in which they were found.
+// r2f: dual slot of every facet rank.  hist[f] = unprocessed elements whose parent is facet f.
+__device__ __forceinline__ int parent_facet(const PolyView &P, int i, const int *__restrict__ r2f)
+{
+    return P.inc_len[i] > 0 ? r2f[P.pool[P.inc_off[i] + P.inc_len[i] - 1]] : 0;
+}
+__global__ __launch_bounds__(PB) void k_unproc_hist(PolyView P, int nv, const int *__restrict__ r2f, int *hist)
+{
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= nv) return;
+    const unsigned char fl = P.flag[i];
+    if (!(fl & F_USED) || (fl & F_SLTN)) return;
+    atomicAdd(&hist[parent_facet(P, i, r2f)], 1);
+}
+// one workgroup walks the histogram from the newest facet down until `want` elements are covered: out[0] = the lowest facet
+// taken, out[1] = elements with a parent facet >= out[0]
+__global__ __launch_bounds__(1024) void k_unproc_threshold(const int *__restrict__ hist, int nf, int want, int *out)
+{
+    __shared__ Tri lds[16];
+    __shared__ int s_carry, s_done;
+    if (threadIdx.x == 0) { s_carry = 0; s_done = 0; }
+    __syncthreads();
+    for (int top = nf; top > 0; top -= 1024) {
+        const int f = top - 1 - (int)threadIdx.x;              // thread 0 takes the newest facet of the window
+        Tri t{f >= 0 ? hist[f] : 0, 0, 0};
+        Tri tot;
+        const Tri ex = block_exscan(t, &tot, lds);
+        const int before = s_carry + ex.a;                     // elements of newer facets
+        if (f >= 0 && before < want && before + t.a >= want) { out[0] = f; out[1] = before + t.a; s_done = 1; }
+        __syncthreads();
+        if (s_done) return;
+        if (threadIdx.x == 0) s_carry += tot.a;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = 0; out[1] = s_carry; }  // fewer than `want` in all
+}
+__global__ __launch_bounds__(PB) void k_unproc_flags_f(PolyView P, int nv, const int *__restrict__ r2f, const int *__restrict__ thr, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    const int i = blockIdx.x * PB + threadIdx.x, fmin = thr[0];
+    Tri t{0, 0, 0};
+    if (i < nv) { const unsigned char fl = P.flag[i]; t.b = (fl & F_USED) && !(fl & F_SLTN); t.a = t.b && parent_facet(P, i, r2f) >= fmin; }      // (.b: all unprocessed elements)
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+// the newest maxout (by slot) of the elements with a parent facet >= thr[0], ascending slot order; parent[] = FACET ids
+__global__ __launch_bounds__(PB) void k_unproc_emit_f(PolyView P, int nv, const int *__restrict__ r2f, const int *__restrict__ thr, const Tri *bpre, int skip, int maxout,
+                                                       int *idx, double *val, unsigned char *fl_out, int *parent)
+{
+    __shared__ Tri lds[16];
+    const int i = blockIdx.x * PB + threadIdx.x, fmin = thr[0];
+    Tri t{0, 0, 0};
+    unsigned char fl = 0;
+    int pf = -1;
+    if (i < nv) { fl = P.flag[i]; if ((fl & F_USED) && !(fl & F_SLTN)) { pf = parent_facet(P, i, r2f); t.a = pf >= fmin; } }
+    Tri tot;
+    const Tri ex = block_exscan(t, &tot, lds);
+    if (i >= nv || !t.a) return;
+    const int pos = bpre[blockIdx.x].a + ex.a - skip;
+    if (pos < 0 || pos >= maxout) return;
+    idx[pos] = i;
+    fl_out[pos] = fl;
+    parent[pos] = P.inc_len[i] > 0 ? pf : -1;
+    for (int k = 0; k < P.d; k++) val[(size_t)pos * P.d + k] = P.X[(size_t)k * P.cap + i];
+}
+// the unprocessed elements whose parent facet is marked in chosen[] (one byte per dual slot >= f0; older facets: not chosen)
+__global__ __launch_bounds__(PB) void k_unproc_flags_c(PolyView P, int nv, const int *__restrict__ r2f, const unsigned char *__restrict__ chosen, int f0, Tri *bsum)
+{
+    __shared__ Tri lds[16];
+    const int i = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    if (i < nv) {
+        const unsigned char fl = P.flag[i];
+        t.b = (fl & F_USED) && !(fl & F_SLTN);
+        if (t.b) { const int f = parent_facet(P, i, r2f); t.a = f >= f0 && chosen[f - f0]; }
+    }
+    Tri tot;
+    (void)block_exscan(t, &tot, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(PB) void k_unproc_emit_c(PolyView P, int nv, const int *__restrict__ r2f, const unsigned char *__restrict__ chosen, int f0, const Tri *bpre, int skip, int maxout,
+                                                       int *idx, double *val, unsigned char *fl_out, int *parent)
+{
+    __shared__ Tri lds[16];
+    const int i = blockIdx.x * PB + threadIdx.x;
+    Tri t{0, 0, 0};
+    unsigned char fl = 0;
+    int pf = -1;
+    if (i < nv) { fl = P.flag[i]; if ((fl & F_USED) && !(fl & F_SLTN)) { pf = parent_facet(P, i, r2f); t.a = pf >= f0 && chosen[pf - f0]; } }
+    Tri tot;
+    const Tri ex = block_exscan(t, &tot, lds);
+    if (i >= nv || !t.a) return;
+    const int pos = bpre[blockIdx.x].a + ex.a - skip;
+    if (pos < 0 || pos >= maxout) return;
+    idx[pos] = i;
+    fl_out[pos] = fl;
+    parent[pos] = pf;
+    for (int k = 0; k < P.d; k++) val[(size_t)pos * P.d + k] = P.X[(size_t)k * P.cap + i];
+}
 __global__ void k_mark(PolyView P, const int *idx, int n, unsigned char bit)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2474,8 +2613,8 @@ struct bslv_poly {
     RoundsBuf *rounds = nullptr;      // scratch of the multi-cut path
     Rounds2Buf *rounds2 = nullptr;    // scratch of the device-selected rounds inside a hot chunk (poly_rounds2_host.inc)
     bool rounds2_enabled = true;      // BSLV_NO_ROUNDS2=1 / bslv_poly_debug_set(h, 6, 0): hot chunks go through the single-cut pipeline
-    bool r2_mis = true;               // rounds take a maximal independent set from the chunk's conflict matrix (BSLV_R2_MIS=0 / debug_set key 11: local minima of one order, round 2)
-    int chunk_cuts = 1024;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
+    bool r2_mis = false;              // BSLV_R2_MIS=1 / debug_set key 11: rounds take a MAXIMAL independent set from a conflict matrix of the chunk (round 3; measured no faster on S-mid)
+    int chunk_cuts = 512;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
     int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
     int r2_min_cuts = 0;              // rounds go on while they hold at least this many cuts on average (debug_set key 8; 0: until the rounds hold one cut each; -1: always)
     long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0, r2_late_left = 0, r2_torn_reads = 0;
@@ -2516,6 +2655,8 @@ struct bslv_poly {
     int *counters = nullptr;          // device, 4 ints
     Tri *totals_h = nullptr; int *counters_h = nullptr;   // pinned
     Mail *mail_h = nullptr, *mail_d = nullptr;          // mapped pinned mailbox (4 entries: round A, -, prune x2)
+    Mail mail_v[4];                                     // verified copies (wait_mail): what the host reads
+    long mail_torn_reads = 0;
     Mail *k2mail_d = nullptr;                           // device memory: where k2_fused leaves its result (2 slots)
     int *fstamp = nullptr, *flocal = nullptr, *nlocal = nullptr; int fcap = 0;   // local facet ids of the cut in flight
     unsigned long long *bits = nullptr; size_t bitscap = 0;                     // local incidence bit matrix
@@ -2555,6 +2696,9 @@ struct bslv_poly {
     unsigned *anyminus = nullptr; int anycap = 0;      // bit b%32 of word b/32: some element violates halfspace b
     int *idx_d = nullptr; double *val_d = nullptr; unsigned char *fl_d = nullptr; int outcap = 0;
     int *par_d = nullptr; int parcap = 0;
+    int *r2f_d = nullptr; int r2fcap = 0, r2f_n = 0;   // dual slot of every facet rank (device copy of facet_of_rank, extended on demand)
+    int *fhist_d = nullptr; int fhistcap = 0;           // unprocessed elements per parent facet + 4 ints of threshold
+    unsigned char *chosen_d = nullptr; size_t chosencap = 0;   // bslv_poly_children_of: one byte per dual slot from the oldest chosen one on
 };
 
 static void v2h_map(const bslv_poly *h, const double *v, int is_dir, double *hp)
@@ -2704,21 +2848,23 @@ static int new_dual(bslv_poly *h, const double *val, int ideal)
 
 // spin on the host mailbox (the scan tail writes it through mapped pinned memory); falls back to a
 // stream synchronise so that a device fault surfaces as an error instead of a hang
+// The verified copy lands in h->mail_v[slot]: nothing reads the mapped memory itself.
 static int wait_mail(bslv_poly *h, int slot, int seq)
 {
     volatile Mail *m = h->mail_h + slot;
-    for (long spin = 0; m->seq != seq; spin++) {
+    long torn = 0, drained = 0;
+    for (long spin = 0; !mail_try_read(m, seq, &h->mail_v[slot], &torn); spin++) {
         if ((spin & 0xFFFF) == 0xFFFF) {
             hipError_t e = hipStreamQuery(h->stream);
-            if (e == hipSuccess) {
-                if (m->seq == seq) break;
-                set_error("poly engine: mailbox %d never reached seq %d", slot, seq);
+            if (e == hipSuccess && ++drained > 64) {            // the stream has long drained: nothing more will arrive
+                set_error("poly engine: mailbox %d never reached a consistent state for seq %d (seq there: %d, %ld torn reads)", slot, seq, (int)m->seq, torn);
                 return BSLV_E_STATE;
             }
-            if (e != hipErrorNotReady) { set_error("poly engine: stream error %s", hipGetErrorString(e)); return BSLV_E_NODEVICE; }
+            if (e != hipSuccess && e != hipErrorNotReady) { set_error("poly engine: stream error %s", hipGetErrorString(e)); return BSLV_E_NODEVICE; }
         }
     }
-    __sync_synchronize();
+    h->mail_torn_reads += torn;
+    if (torn) { static const bool rep = getenv("BSLV_R2_REPORT") != nullptr; if (rep) fprintf(stderr, "poly: mailbox %d seq %d arrived before its content: %ld reads repeated\n", slot, seq, torn); }
     return 0;
 }
 
@@ -2811,7 +2957,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     }
     HIP_TRY(hipGetLastError());
     if ((rc = wait_mail(h, 2, seq))) return rc;
-    const Tri tp = h->mail_h[2].t;
+    const Tri tp = h->mail_v[2].t;
     if (shard) {
         // this rank's pairs into a staging list, counts and pairs all-gathered (8 bytes per pair, carried as the bit pattern of a double)
         const int world = bslv_dist_world();
@@ -2867,12 +3013,12 @@ static int settle_k2(bslv_poly *h, bool *redo = nullptr)
     if (!h->pend_k2) return 0;
     int rc;
     Tri tp;
-    if (h->mail_h[0].k2seq == h->pend_seq) tp = h->mail_h[0].k2t;          // came with the mailbox of the round A behind it
+    if (h->mail_v[0].k2seq == h->pend_seq) tp = h->mail_v[0].k2t;          // came with the mailbox of the round A behind it
     else {
         hipLaunchKernelGGL(k_forward_mail, dim3(1), dim3(1), 0, h->stream, (const Mail *)(h->k2mail_d + (h->pend_slot - 2)), h->mail_d + h->pend_slot);
         HIP_TRY(hipGetLastError());
         if ((rc = wait_mail(h, h->pend_slot, h->pend_seq))) return rc;
-        tp = h->mail_h[h->pend_slot].t;
+        tp = h->mail_v[h->pend_slot].t;
     }
     h->pend_k2 = false;
     h->ne = h->pend_ebase;
@@ -3011,12 +3157,12 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         h->tm_launch[3] += std::chrono::duration<double, std::micro>(tl4 - tl3).count();
         bool redo;
         if ((rc = settle_k2(h, &redo))) return rc;
-        if (!redo && spec && h->mail_h[0].cnt[0] > 0) {
+        if (!redo && spec && h->mail_v[0].cnt[0] > 0) {
             // did the device decline round B for want of capacity?  Then its classification of the NEXT halfspace has
             // already overwritten the classes of this one: book the declined prune, grow, and run the cut again
             // without speculation
-            const Tri t0 = h->mail_h[0].t;
-            const int zub = h->mail_h[0].cnt[2];
+            const Tri t0 = h->mail_v[0].t;
+            const int zub = h->mail_v[0].cnt[2];
             if (!(t0.b <= h->cross_ub && nv0 + t0.b <= h->P.cap && (unsigned long long)h->poolused + (unsigned)t0.c + (unsigned)zub <= h->poolcap)) {
                 h->pend_k2 = true; h->pend_seq = seqB; h->pend_slot = slotB; h->pend_ebase = h->ne; h->pend_ncross = 0;
                 if ((rc = settle_k2(h))) return rc;
@@ -3036,10 +3182,10 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
     }
     const ZMarks Z{h->zlist + ZMAX * cslot, h->zrows, h->fcap, cut_id};
     const int *counters = h->counters + CSTRIDE * cslot;
-    const int nminus = h->mail_h[0].cnt[0], nzero = h->mail_h[0].cnt[1], zero_ub = h->mail_h[0].cnt[2];
-    const Tri te = h->mail_h[0].t;
+    const int nminus = h->mail_v[0].cnt[0], nzero = h->mail_v[0].cnt[1], zero_ub = h->mail_v[0].cnt[2];
+    const Tri te = h->mail_v[0].t;
     const int ne0 = h->ne;
-    if (h->mail_h[0].cnt[3] != ne0) { set_error("internal: edge count on the device %d, on the host %d", h->mail_h[0].cnt[3], ne0); return BSLV_E_STATE; }
+    if (h->mail_v[0].cnt[3] != ne0) { set_error("internal: edge count on the device %d, on the host %d", h->mail_v[0].cnt[3], ne0); return BSLV_E_STATE; }
     if (h->cutlog) fprintf(h->cutlog, "%d %d %d %d %d %d %d %d\n", nv0, ne0, nminus, nzero, zero_ub, te.a, te.b, te.c);
     const int nsurv = te.a, ncross = te.b;
     const int nm = nzero + ncross;
@@ -3277,6 +3423,9 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
         set_error("allocation of scan scratch failed");
         return fail(BSLV_E_NOMEM);
     }
+    memset((void *)h->mail_h, 0, 4 * sizeof(Mail));
+    memset((void *)h->mail_v, 0, sizeof h->mail_v);
+    for (int k = 0; k < 4; k++) h->mail_h[k].chk2 = mail_sum2(Tri{0, 0, 0}, 0);      // (the prune triple of a mailbox nobody has written yet is consistent)
     // k2_fused keeps the local incidence bit matrix in LDS: ask for most of the CU's 160 KB, settle for 48 KB
     h->k2_lds = 128 * 1024;
     if (hipFuncSetAttribute((const void *)k2_fused_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess ||
@@ -3289,7 +3438,6 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
     if (getenv("BSLV_NO_ROUNDS2")) h->rounds2_enabled = false;
     if (const char *e = getenv("BSLV_R2_MIS")) h->r2_mis = atoi(e) != 0;
-    if (!h->r2_mis) h->chunk_cuts = 512;
     if (const char *e = getenv("BSLV_CHUNK_CUTS")) h->chunk_cuts = std::min(4096, std::max(32, atoi(e)));
     if (const char *e = getenv("BSLV_R2_MIN_CUTS")) h->r2_min_cuts = std::max(-1, atoi(e));
     if (const char *e = getenv("BSLV_R2_RULE")) h->r2_rule = atoi(e) ? 1 : 0;
@@ -3327,7 +3475,7 @@ void bslv_poly_destroy(bslv_poly *h)
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->fm_cnt); fr(h->fm_list); fr(h->nzlist); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
-    fr(h->shard_e); fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d);
+    fr(h->shard_e); fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d); fr(h->r2f_d); fr(h->fhist_d); fr(h->chosen_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
     if (h->rounds2) { rounds2_free(*h->rounds2); delete h->rounds2; }
     if (h->totals_h) (void)hipHostFree(h->totals_h);
@@ -3541,12 +3689,15 @@ int bslv_poly_classify_batch_touch(bslv_poly *h, int B, const double *hps, unsig
 // all unprocessed elements (used && !sltn) in ascending slot order: the set poly__get_vrtx
 // iterates (bslv_poly.c:214-216).  *count = how many exist; at most max_out are written.
 int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
+static int sync_r2f(bslv_poly *h);
 int bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count)
 {
     return bslv_poly_unprocessed2(h, max_out, 0, idx, val, ideal, nullptr, count);
 }
 // from_end == 1: the max_out NEWEST unprocessed elements (highest slots); == 2: max_out elements spread
-// evenly over all unprocessed ones (every total/max_out-th); parent[k] = newest facet
+// evenly over all unprocessed ones (every total/max_out-th); == 3: the children of the newest cuts first (by the
+// dual slot of the newest facet through them; fewer than max_out may come back while count says more exist --
+// never zero); parent[k] = newest facet
 // through element k (the cut that created it), -1 if none
 int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count)
 {
@@ -3556,6 +3707,64 @@ int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, do
     int rc;
     const int nv = h->nv, nb = (nv + PB - 1) / PB;
     if ((rc = ensure_bsum(h, nb + 1))) return rc;
+    if (from_end == 3) {
+        // children of the newest cuts first: at most max_out elements, those whose parent facet is newest (whole families of
+        // siblings; of the oldest family taken, the newest members by slot).  *count = all unprocessed elements, as in the other modes.
+        hipStream_t s = h->stream;
+        const int nf = h->nf;
+        if ((rc = sync_r2f(h))) return rc;
+        if (nf + 4 > h->fhistcap) { const int nc = std::max(nf + 4 + 4096, h->fhistcap * 2); if ((rc = grow(&h->fhist_d, 0, (size_t)nc, s))) return rc; h->fhistcap = nc; }
+        int *thr = h->fhist_d + h->fhistcap - 4;
+        HIP_TRY(hipMemsetAsync(h->fhist_d, 0, (size_t)h->fhistcap * sizeof(int), s));
+        hipLaunchKernelGGL(k_unproc_hist, dim3(nb), dim3(PB), 0, s, h->P, nv, (const int *)h->r2f_d, h->fhist_d);
+        // (max_out == 0: only the count is wanted -- the threshold facet 0 covers everything)
+        hipLaunchKernelGGL(k_unproc_threshold, dim3(1), dim3(1024), 0, s, (const int *)h->fhist_d, nf, max_out > 0 ? max_out : (1 << 30), thr);
+        hipLaunchKernelGGL(k_unproc_flags_f, dim3(nb), dim3(PB), 0, s, h->P, nv, (const int *)h->r2f_d, (const int *)thr, h->bsum);
+        Tri t;
+        if ((rc = scan_totals(h, nb, &t))) return rc;
+        *count = t.b;
+        if (max_out == 0 || !idx) return 0;
+        // everything from the threshold facet up, capped at 2 max_out + 4096 (newest slots); the host keeps the max_out best
+        const int cap = 2 * max_out + 4096, n = std::min(t.a, cap);
+        if (n > h->outcap) {
+            int nc = std::max(n, h->outcap * 2);
+            if ((rc = grow(&h->idx_d, 0, (size_t)nc, s))) return rc;
+            if ((rc = grow(&h->val_d, 0, (size_t)nc * h->d, s))) return rc;
+            if ((rc = grow(&h->fl_d, 0, (size_t)nc, s))) return rc;
+            h->outcap = nc;
+        }
+        if (n > h->parcap) { if ((rc = grow(&h->par_d, 0, (size_t)std::max(n, h->parcap * 2), s))) return rc; h->parcap = std::max(n, h->parcap * 2); }
+        hipLaunchKernelGGL(k_unproc_emit_f, dim3(nb), dim3(PB), 0, s, h->P, nv, (const int *)h->r2f_d, (const int *)thr, (const Tri *)h->bsum, t.a - n, n, h->idx_d, h->val_d, h->fl_d, h->par_d);
+        HIP_TRY(hipGetLastError());
+        std::vector<int> ti(n), tp(n);
+        std::vector<double> tv((size_t)n * h->d);
+        std::vector<unsigned char> fl(n);
+        HIP_TRY(hipMemcpyAsync(ti.data(), h->idx_d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(tp.data(), h->par_d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(tv.data(), h->val_d, (size_t)n * h->d * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(fl.data(), h->fl_d, (size_t)n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<int> ord(n);
+        for (int k = 0; k < n; k++) ord[k] = k;
+        // newest parent facet first, within a family the newest slot first; ideal elements first of all (they cost no LP)
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+            const bool ia = fl[a] & F_IDEAL, ib = fl[b] & F_IDEAL;
+            if (ia != ib) return ia;
+            if (tp[a] != tp[b]) return tp[a] > tp[b];
+            return ti[a] > ti[b];
+        });
+        const int m = std::min(n, max_out);
+        ord.resize(m);
+        std::sort(ord.begin(), ord.end(), [&](int a, int b) { return ti[a] < ti[b]; });      // handed on in ascending slot order, as in the other modes
+        for (int k = 0; k < m; k++) {
+            const int o = ord[k];
+            idx[k] = ti[o];
+            if (val) memcpy(val + (size_t)k * h->d, &tv[(size_t)o * h->d], h->d * sizeof(double));
+            if (ideal) ideal[k] = (fl[o] & F_IDEAL) ? 1 : 0;
+            if (parent) parent[k] = tp[o];
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(k_unproc_flags, dim3(nb), dim3(PB), 0, h->stream, h->P, nv, h->bsum);
     Tri t;
     if ((rc = scan_totals(h, nb, &t))) return rc;
@@ -3581,6 +3790,92 @@ int bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, do
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (ideal) for (int k = 0; k < n; k++) ideal[k] = (fl[k] & F_IDEAL) ? 1 : 0;
     if (parent) for (int k = 0; k < n; k++) if (parent[k] >= 0) parent[k] = h->facet_of_rank[parent[k]];
+    return 0;
+}
+
+static int sync_r2f(bslv_poly *h)
+{
+    hipStream_t s = h->stream;
+    int rc;
+    const int nr = (int)h->facet_of_rank.size();
+    if (nr > h->r2fcap) { const int nc = std::max(nr + 4096, h->r2fcap * 2); if ((rc = grow(&h->r2f_d, (size_t)h->r2f_n, (size_t)nc, s))) return rc; h->r2fcap = nc; }
+    if (nr > h->r2f_n) { HIP_TRY(hipMemcpyAsync(h->r2f_d + h->r2f_n, h->facet_of_rank.data() + h->r2f_n, (size_t)(nr - h->r2f_n) * sizeof(int), hipMemcpyHostToDevice, s)); h->r2f_n = nr; }
+    return 0;
+}
+// Batch selection by FAMILIES (the unprocessed children of one cut; bslv_benson policy 6).  counts[k] = unprocessed elements whose
+// parent -- the newest facet through them -- is dual slot first_facet + k, k < n; *total = all unprocessed elements,
+// *older = those whose parent is older than first_facet.
+int bslv_poly_children_hist(bslv_poly *h, int first_facet, int n, int *counts, int *total, int *older)
+{
+    if (!h || first_facet < 0 || n < 0 || (n > 0 && !counts)) { set_error("bslv_poly_children_hist: bad argument"); return BSLV_E_ARG; }
+    if (total) *total = 0;
+    if (older) *older = 0;
+    for (int k = 0; k < n; k++) counts[k] = 0;
+    if (!h->initialised || h->nv == 0) return 0;
+    hipStream_t s = h->stream;
+    int rc;
+    const int nv = h->nv, nb = (nv + PB - 1) / PB, nf = h->nf;
+    if ((rc = sync_r2f(h))) return rc;
+    if (nf + 4 > h->fhistcap) { const int nc = std::max(nf + 4 + 4096, h->fhistcap * 2); if ((rc = grow(&h->fhist_d, 0, (size_t)nc, s))) return rc; h->fhistcap = nc; }
+    HIP_TRY(hipMemsetAsync(h->fhist_d, 0, (size_t)nf * sizeof(int), s));
+    hipLaunchKernelGGL(k_unproc_hist, dim3(nb), dim3(PB), 0, s, h->P, nv, (const int *)h->r2f_d, h->fhist_d);
+    HIP_TRY(hipGetLastError());
+    const int m = std::max(0, std::min(n, nf - first_facet));
+    if (m > 0) HIP_TRY(hipMemcpyAsync(counts, h->fhist_d + first_facet, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (total || older) {
+        // (the histogram itself is small: summed on the host)
+        std::vector<int> all(nf);
+        HIP_TRY(hipMemcpyAsync(all.data(), h->fhist_d, (size_t)nf * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        long t = 0, o = 0;
+        for (int f = 0; f < nf; f++) { t += all[f]; if (f < first_facet) o += all[f]; }
+        if (total) *total = (int)t;
+        if (older) *older = (int)o;
+    } else HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+// the unprocessed children of the facets facets[0..nfacets) (dual slots, all >= the smallest of them), at most max_out (the newest
+// slots), in ascending slot order; parent[k] = dual slot of the parent; *n_out = how many were written
+int bslv_poly_children_of(bslv_poly *h, int nfacets, const int *facets, int max_out, int *idx, double *val, int *ideal, int *parent, int *n_out)
+{
+    if (!h || nfacets < 0 || (nfacets > 0 && !facets) || max_out < 0 || !n_out || (max_out > 0 && !idx)) { set_error("bslv_poly_children_of: bad argument"); return BSLV_E_ARG; }
+    *n_out = 0;
+    if (!h->initialised || h->nv == 0 || nfacets == 0 || max_out == 0) return 0;
+    hipStream_t s = h->stream;
+    int rc;
+    const int nv = h->nv, nb = (nv + PB - 1) / PB, nf = h->nf;
+    int f0 = nf;
+    for (int k = 0; k < nfacets; k++) { if (facets[k] < 0 || facets[k] >= nf) { set_error("bslv_poly_children_of: facet %d out of range", facets[k]); return BSLV_E_ARG; } f0 = std::min(f0, facets[k]); }
+    std::vector<unsigned char> chosen((size_t)(nf - f0), 0);
+    for (int k = 0; k < nfacets; k++) chosen[facets[k] - f0] = 1;
+    if ((rc = sync_r2f(h))) return rc;
+    if ((size_t)(nf - f0) > h->chosencap) { const size_t nc = std::max((size_t)(nf - f0) + 4096, h->chosencap * 2); if ((rc = grow(&h->chosen_d, 0, nc, s))) return rc; h->chosencap = nc; }
+    HIP_TRY(hipMemcpyAsync(h->chosen_d, chosen.data(), chosen.size(), hipMemcpyHostToDevice, s));
+    if ((rc = ensure_bsum(h, nb + 1))) return rc;
+    hipLaunchKernelGGL(k_unproc_flags_c, dim3(nb), dim3(PB), 0, s, h->P, nv, (const int *)h->r2f_d, (const unsigned char *)h->chosen_d, f0, h->bsum);
+    Tri t;
+    if ((rc = scan_totals(h, nb, &t))) return rc;          // (synchronises: `chosen` may go)
+    const int n = std::min(t.a, max_out);
+    if (n == 0) return 0;
+    if (n > h->outcap) {
+        int nc = std::max(n, h->outcap * 2);
+        if ((rc = grow(&h->idx_d, 0, (size_t)nc, s))) return rc;
+        if ((rc = grow(&h->val_d, 0, (size_t)nc * h->d, s))) return rc;
+        if ((rc = grow(&h->fl_d, 0, (size_t)nc, s))) return rc;
+        h->outcap = nc;
+    }
+    if (n > h->parcap) { if ((rc = grow(&h->par_d, 0, (size_t)std::max(n, h->parcap * 2), s))) return rc; h->parcap = std::max(n, h->parcap * 2); }
+    hipLaunchKernelGGL(k_unproc_emit_c, dim3(nb), dim3(PB), 0, s, h->P, nv, (const int *)h->r2f_d, (const unsigned char *)h->chosen_d, f0, (const Tri *)h->bsum, t.a - n, n,
+                       h->idx_d, h->val_d, h->fl_d, h->par_d);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned char> fl(n);
+    if (parent) HIP_TRY(hipMemcpyAsync(parent, h->par_d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(idx, h->idx_d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (val) HIP_TRY(hipMemcpyAsync(val, h->val_d, (size_t)n * h->d * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(fl.data(), h->fl_d, (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ideal) for (int k = 0; k < n; k++) ideal[k] = (fl[k] & F_IDEAL) ? 1 : 0;
+    *n_out = n;
     return 0;
 }
 
@@ -3644,7 +3939,77 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
 }
 long bslv_poly_sharded_prunes(const bslv_poly *h) { return h ? h->n_sharded : 0; }
 long bslv_poly_rounds2_late_left(const bslv_poly *h) { return h ? h->r2_late_left : 0; }
-long bslv_poly_rounds2_torn_reads(const bslv_poly *h) { return h ? h->r2_torn_reads : 0; }
+long bslv_poly_rounds2_torn_reads(const bslv_poly *h) { return h ? h->r2_torn_reads + h->mail_torn_reads : 0; }      // (both kinds of mailbox)
+
+// Host-only self-test of the two mailbox readers (no GPU): a writer thread publishes `rounds` messages the WRONG way round --
+// the sequence number first, the content afterwards, word by word -- into plain host memory, the reader takes them with
+// mail_try_read / rstate_try_read.  Every message's content is a function of its sequence number, so a reader that accepted
+// old content under a new number is caught.  which: 0 = Mail (one-cut pipeline), 1 = RState (rounds).  Returns 0 and the number
+// of reads that had to be repeated in *torn_out, or -1 - (number of messages accepted with foreign content).
+int bslv_selftest_mailbox(int which, int rounds, long *torn_out)
+{
+    if (rounds < 1 || which < 0 || which > 1) return BSLV_E_ARG;
+    long torn = 0, bad = 0;
+    std::atomic<int> ack{0};
+    if (which == 0) {
+        Mail *box = new Mail();
+        memset((void *)box, 0, sizeof *box);
+        box->chk2 = mail_sum2(Tri{0, 0, 0}, 0);
+        volatile Mail *m = box;
+        std::thread writer([&] {
+            for (int q = 1; q <= rounds; q++) {
+                while (ack.load(std::memory_order_acquire) != q - 1) { }
+                const int c4[4] = {q, 2 * q, 3 * q, 4 * q};
+                const Tri t{5 * q, 6 * q, 7 * q}, k2{8 * q, 9 * q, 10 * q};
+                m->seq = q;                                             // the number first ...
+                __sync_synchronize();
+                for (int k = 0; k < 4; k++) { m->cnt[k] = c4[k]; for (volatile int d = 0; d < 50; d++) { } }
+                const_cast<Mail *>(box)->t = t; const_cast<Mail *>(box)->k2t = k2; m->k2seq = 11 * q;
+                for (volatile int d = 0; d < 200; d++) { }
+                m->chk2 = mail_sum2(k2, 11 * q);
+                m->chk = mail_sum(c4, t, q);                            // ... the checksum last
+            }
+        });
+        for (int q = 1; q <= rounds; q++) {
+            Mail got;
+            while (!mail_try_read(m, q, &got, &torn)) { }
+            if (got.cnt[0] != q || got.cnt[3] != 4 * q || got.t.a != 5 * q || got.t.c != 7 * q || got.k2t.b != 9 * q || got.k2seq != 11 * q) bad++;
+            ack.store(q, std::memory_order_release);
+        }
+        writer.join();
+        delete box;
+    } else {
+        RState *box = new RState();
+        memset((void *)box, 0, sizeof *box);
+        volatile RState *m = box;
+        std::thread writer([&] {
+            for (int q = 1; q <= rounds; q++) {
+                while (ack.load(std::memory_order_acquire) != q - 1) { }
+                RState st;
+                memset((void *)&st, 0, sizeof st);
+                st.round = q; st.S = 3 * q; st.nalive = 5 * q; st.napplied = 7 * q; st.ne_next = 11 * q; st.err_d[11] = 13.0 * q;
+                st.chk = rstate_sum(st, q);
+                m->seq = q;                                             // the number first ...
+                __sync_synchronize();
+                const unsigned *src = reinterpret_cast<const unsigned *>(&st);
+                volatile unsigned *dst = reinterpret_cast<volatile unsigned *>(box);
+                const size_t seq_word = offsetof(RState, seq) / 4, chk_word = offsetof(RState, chk) / 4;
+                for (size_t w = 0; w < sizeof(RState) / 4; w++) { if (w == seq_word || w == chk_word) continue; dst[w] = src[w]; for (volatile int d = 0; d < 10; d++) { } }
+                dst[chk_word] = st.chk;                                 // ... the checksum last
+            }
+        });
+        for (int q = 1; q <= rounds; q++) {
+            RState got;
+            while (!rstate_try_read(m, q, &got, &torn)) { }
+            if (got.round != q || got.S != 3 * q || got.nalive != 5 * q || got.napplied != 7 * q || got.ne_next != 11 * q || got.err_d[11] != 13.0 * q) bad++;
+            ack.store(q, std::memory_order_release);
+        }
+        writer.join();
+        delete box;
+    }
+    if (torn_out) *torn_out = torn;
+    return bad ? (int)(-1 - bad) : 0;
+}
 int bslv_poly_path_stats(const bslv_poly *h, long out[6])
 {
     if (!h || !out) return BSLV_E_ARG;

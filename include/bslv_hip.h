@@ -164,6 +164,10 @@ int  bslv_poly_init(bslv_poly *h, int *rc_out);               /* poly__intl_appr
 int  bslv_poly_next(bslv_poly *h, double *val, int *ideal, int *idx, int *rc_out); /* poly__get_vrtx :210 */
 int  bslv_poly_unprocessed(bslv_poly *h, int max_out, int *idx, double *val, int *ideal, int *count);
 int  bslv_poly_unprocessed2(bslv_poly *h, int max_out, int from_end, int *idx, double *val, int *ideal, int *parent, int *count);
+/* families: counts[k] = unprocessed elements whose parent (the newest facet through them) is dual slot first_facet + k; the
+ * unprocessed children of a list of facets (at most max_out, the newest slots, ascending; parent[] = dual slots) */
+int  bslv_poly_children_hist(bslv_poly *h, int first_facet, int n, int *counts, int *total, int *older);
+int  bslv_poly_children_of(bslv_poly *h, int nfacets, const int *facets, int max_out, int *idx, double *val, int *ideal, int *parent, int *n_out);
 int  bslv_poly_mark(bslv_poly *h, int n, const int *idx);     /* ST_BT(primal.sltn, idx) */
 int  bslv_poly_dual_adjacency(bslv_poly *h);                  /* poly__update_adjacence(&dual) :992 */
 /* batched incidence kernel on the current elements: hps = B x (dim+1) halfspaces (normal, alpha);
@@ -194,6 +198,10 @@ int  bslv_poly_get_dual(bslv_poly *h, unsigned char *used, unsigned char *ideal,
 int  bslv_poly_get_edges(bslv_poly *h, int *ab);
 int  bslv_poly_get_inc(bslv_poly *h, int *pairs);
 int  bslv_poly_get_dual_edges(bslv_poly *h, int *ab);
+/* host-only self-test of the two mailbox readers of the polyhedron engine (no GPU needed): a writer thread publishes `rounds`
+ * messages with the sequence number FIRST and the content afterwards; 0 = every message was taken with its own content
+ * (*torn_out: reads that had to be repeated), negative = a reader accepted foreign content.  which: 0 Mail, 1 round state */
+int  bslv_selftest_mailbox(int which, int rounds, long *torn_out);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Batched Benson phase-2 driver  (replaces phase2_primal's loop, bslv_algs.c:958-1082,
@@ -247,6 +255,10 @@ int  bslv_benson_set_sibling_rule(bslv_benson *h, int cap, int window);
 /* policy 4: K depth-first fronts (a vertex belongs to the front of the cut that created it, a cut to the front of the vertex
  * whose LP returned it; newest first inside a front, at most sib_cap children of one cut per front and batch) */
 int  bslv_benson_set_fronts(bslv_benson *h, int nfronts, int sib_cap);
+/* policy 5: the children of the newest cuts first (by the dual slot of the cut, not by the element's own slot);
+ * policy 6: whole families -- all unprocessed children of a cut -- of parents chosen among the cuts of the last `batches` outer
+ * iterations: mode 0 newest cuts first, 1 pseudo-random, 2 far apart (farthest-point sampling on the cuts' normals) */
+int  bslv_benson_set_families(bslv_benson *h, int mode, int batches);
 /* tuning hooks (no counterpart in the reference): the caller chooses the batch itself -- elements with their coordinates and
  * parent facets as bslv_poly_unprocessed2 returns them -- and reads, per LP of this rank's last solve_local, the warm-start slot
  * (0 = root tableau), the pivots and the generation of the new slot; returns the number of entries written */

@@ -84,7 +84,10 @@ def test_s_small_complete_run_matches_oracle():
     got = ph.canonical(eng.poly_dump(), decimals=6)
     paths = eng.poly_call("path_stats")
     r2 = eng.poly_call("rounds2_stats")
+    health = eng.poly_call("rounds2_health")
     eng.close()
+    # no cut was ever left alive when a chunk's rounds said 'none alive' (an error since round 3; the counter stays as a witness)
+    assert health["late_left"] == 0, health
     # ALLOW-LIST: 8237 vertices / 8186 facets on both sides; measured 10 points (both directions summed) without a partner
     # within 1e-6 and one edge more on one side.  Both runs stop at eps = 1e-9 = the polyhedron code's own on-plane band
     # (bslv_poly.h:47; a smaller eps makes the REFERENCE loop forever: poly__add_vrtx's EXIT_FAILURE is ignored at

@@ -130,7 +130,8 @@ R2_MODES = {
     "rounds, small chunks": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_CHUNK_CUTS": "64"},
     "rounds, every prune through the multi-kernel path": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_K2_LDS": "64"},
     "rounds without speculation in the tail": {"BSLV_NO_SPEC": "1"},
-    "rounds by the local-minima rule of round 2 (no conflict matrix)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "0"},
+    "rounds that take a maximal independent set from a conflict matrix": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "1"},
+    "conflict matrix, chunks of 1024": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "1", "BSLV_CHUNK_CUTS": "1024"},
 }
 
 
@@ -197,7 +198,9 @@ def _smid_cut_sequence(steps):
         rec, piv, ls = eng.solve_local(nl)
         eng.apply(rec)
     D = eng.poly_dump()
+    health = eng.poly_call("rounds2_health")
     eng.close()
+    assert health["late_left"] == 0, health         # (every chunk's rounds ended with nothing alive; torn reads are repeated, not hidden)
     return prob["q"], np.ones(prob["q"]), D["Y"], D
 
 
