@@ -86,6 +86,12 @@ def main():
         # torch.distributed hands out the communicator id and does the barrier / max-over-ranks of the timing
         from bensolve_amd.benson import dist_init_rccl
         transport = dist_init_rccl(dist, device)
+        if not transport.startswith("ncclAllGather"):
+            # LOUD: the data-path collective is meant to be RCCL inside the library; anything else is a different measurement
+            print("bench.py: rank %d: RCCL transport NOT in use: %s" % (rank, transport), file=sys.stderr)
+            if not os.environ.get("BSLV_BENCH_ALLOW_FALLBACK"):
+                raise SystemExit("bench.py --gpus %d: the library's RCCL communicator could not be created on every rank (%s); "
+                                 "set BSLV_BENCH_ALLOW_FALLBACK=1 to measure the torch.distributed fallback instead" % (world, transport))
 
     if args.steps is None:
         args.steps = 3 if args.workload == "S-degenerate" else 20     # (the rate moves with the window: waves of redundant LPs -- 5-step windows gave 62 k .. 108 k LPs/s on S-mid; 20 steps average over them)
@@ -170,9 +176,12 @@ def main():
     upd_ms = 0.0
     lp_ms = 0.0
     sync()
+    step_t = []                          # host clock at the end of every timed step (for the spread of the rate over windows)
+    step_lps = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         s = one_step()
+        step_t.append(time.perf_counter()); step_lps.append(s["lps"])
         lps += s["lps"]
         cuts += s["cuts"]
         redundant += s.get("redundant", 0)
@@ -191,18 +200,30 @@ def main():
     pair_tests = c1["pair_tests"] - pt0
     live = int(eng.poly_dump()["pu"].sum()) if c1["nprimal"] < 5_000_000 else -1
 
+    # spread of the headline: the rate over consecutive windows of the timed region (>= 3 windows; rank 0's clock)
+    nwin = min(5, args.steps) if args.steps >= 3 else 1
+    win_rates = []
+    for wdx in range(nwin):
+        a, b = wdx * args.steps // nwin, (wdx + 1) * args.steps // nwin
+        if b > a:
+            ta = t0 if a == 0 else step_t[a - 1]
+            win_rates.append(sum(step_lps[a:b]) / max(step_t[b - 1] - ta, 1e-9))
+    win_rates.sort()
+    starts = eng.start_stats()
     # max over ranks of the elapsed time; sums of the per-rank pivot counts
     if world > 1:
         cdev = torch.device("cpu") if rehearsal else device       # (gloo: host tensors)
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        agg = torch.tensor([pivots, upd_ms], dtype=torch.float64, device=cdev)
+        agg = torch.tensor([pivots, upd_ms, eng.totals()["lps"], starts["root"], starts["nearest"]], dtype=torch.float64, device=cdev)
         allp = [torch.zeros_like(agg) for _ in range(world)]
         dist.all_gather(allp, agg)
         pivots_all = sum(float(a[0]) for a in allp)
+        per_rank = [{"rank": r, "pivots": int(a[0]), "starts_from_root_tableau": int(a[3]), "starts_from_nearest_tableau": int(a[4])} for r, a in enumerate(allp)]
     else:
         pivots_all = pivots
+        per_rank = [{"rank": 0, "pivots": int(pivots), "starts_from_root_tableau": starts["root"], "starts_from_nearest_tableau": starts["nearest"]}]
 
     # Dominant kernel: k_flush, one pass over the tableau of every LP that has pivots pending (delayed update: up to 6 pivots
     # are selected on vectors, then applied together).  Unit = one (LP, pass); algorithmic bytes per unit = one read + one
@@ -216,7 +237,9 @@ def main():
     # HBM traffic from the PMC counters: collected in separate rocprofv3 --pmc passes (profiles/r01_pmc_k_flush.json,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per tableau pass; scaled to this run's passes per launch
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_k_flush.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_k_flush.json")
+    if not os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_k_flush.json")
     if args.workload == "S-mid" and os.path.exists(pmc_file):
         per_pass = json.load(open(pmc_file))["k_flush"]["traffic_bytes_per_pass"]
         traffic = round(per_pass * passes / launches, 0)
@@ -296,6 +319,8 @@ def main():
         out = {
             "metric": "scalar LPs/sec (Benson phase 2, batched P2(v) solves incl. cut application), synthetic VLP q=%d n=%d m=%d" % (q, n, m),
             "value": round(lps / dt, 2), "unit": "LPs/s",
+            "value_min": round(win_rates[0], 2) if win_rates else None, "value_median": round(win_rates[len(win_rates) // 2], 2) if win_rates else None,
+            "value_max": round(win_rates[-1], 2) if win_rates else None, "value_windows": len(win_rates),
             "useful_lps_per_sec": round((cuts + confirmed) / dt, 2), "lps_redundant_frac": round(1.0 - (cuts + confirmed) / max(lps, 1), 4),
             "useful_note": "useful = LPs whose outcome changed the state (cut applied or vertex confirmed); the rest returned a cut that an earlier LP of the same batch had already delivered.  The reference's sequential loop solves only useful LPs (bslv_algs.c:1030-1080): compare useful_lps_per_sec with cpu_baseline.value", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -309,6 +334,8 @@ def main():
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
             "live_vertices": live, "poly_rounds": eng.poly_call("rounds_run") - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": {"collect": round(phase_ms[0] / args.steps, 2), "lp": round(phase_ms[1] / args.steps, 2), "cuts": round(phase_ms[2] / args.steps, 2)}, "update_kernel_ms_rank0": round(upd_ms, 2),
+            "warm_starts": {"per_rank": per_rank, "note": "LPs whose parent's tableau was not resident on the rank that solved them start from the nearest resident tableau (else from the root tableau): the hit rate of the dealing rule"},
+            "useful_vs_cpu_baseline": round(((cuts + confirmed) / dt) / cpu["value"], 1) if cpu and cpu.get("value") else None,
             "roofline": roofline, "roofline_cuts": roofline_cuts, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -167,6 +167,12 @@ class BensonEngine:
         check(self.lib.bslv_benson_totals(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return dict(lps=a.value, cuts=b.value, pivots=c.value)
 
+    def start_stats(self):
+        a, b = ctypes.c_long(), ctypes.c_long()
+        self.lib.bslv_benson_start_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        check(self.lib.bslv_benson_start_stats(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return dict(root=a.value, nearest=b.value)
+
     def run(self, max_batch, max_steps=None):
         """run to termination (poly__get_vrtx returns 'none left', bslv_algs.c:1032-1035)"""
         steps = 0

@@ -33,6 +33,8 @@ struct bslv_benson {
     int rows_folded = 0;                              // singleton rows of A turned into column bounds
     bool hom = false;                                 // homogeneous problem (phases 0 and 1)
     long tot_retries = 0;                             // LPs solved again from the root tableau / the standard basis
+    long tot_root_starts = 0, tot_nearest_starts = 0; // LPs whose parent's tableau was not resident here: started from the root tableau / from the nearest resident one
+    bool nearest_start = true;
     // option -s (opt->solution == PRE_IMG_ON): x of every confirmed vertex, (u, w) of every cut (bslv_algs.c:1064-1079)
     bool want_primg = false;
     int m_orig = 0;                                   // rows of A as given (pre-images need every row: no presolve)
@@ -561,15 +563,26 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
     // warm-start source: the tableau of the LP whose cut created the vertex; if that was evicted, the
     // resident tableau whose own vertex is nearest (every optimal tableau is dual feasible for every v)
     std::vector<int> cand;
-    if (h->policy == 2) {
-        const int step = std::max(1, (int)h->parents.size() / 768);
+    // a vertex whose parent's tableau is not here -- evicted, or (several ranks) solved on another rank and dealt to this one
+    // because its owner was full -- starts from the resident tableau whose own vertex is nearest, not from the root tableau: any
+    // optimal tableau is dual feasible for every v, and a neighbour's is a few pivots away where the root's is hundreds
+    bool cand_built = false;
+    auto build_cand = [&]() {                         // (only when a parent is missing: the walk over the resident parents is not free)
+        cand_built = true;
+        if (!(h->policy == 2 || h->world > 1 || h->nearest_start)) return;
+        const int step = std::max(1, (int)h->parents.size() / 1024);
         int c = 0;
-        for (auto &pr : h->parents) if ((c++ % step) == 0 && pr.first >= 0 && h->slot_valid[pr.second]) cand.push_back(pr.second);
-    }
+        for (auto &pr : h->parents) {
+            if ((c++ % step) != 0 || pr.first < 0 || !h->slot_valid[pr.second]) continue;
+            auto fs = h->facet_slot.find(pr.first);
+            if (fs != h->facet_slot.end() && fs->second == pr.second) cand.push_back(pr.second);
+        }
+    };
     for (int k = 0; k < nl; k++) {
         int f = B.b_parent[B.l_pos[k]];
         auto it = h->facet_slot.find(f);
         src[k] = (it != h->facet_slot.end()) ? it->second : 0;
+        if (it == h->facet_slot.end() && !cand_built) build_cand();
         if (it == h->facet_slot.end() && !cand.empty()) {
             const double *v = &B.b_val[(size_t)B.l_pos[k] * q];
             double best = INFINITY; int bs = 0;
@@ -580,7 +593,8 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
                 if (dd < best) { best = dd; bs = s; }
             }
             src[k] = bs;
-        }
+            h->tot_nearest_starts++;
+        } else if (it == h->facet_slot.end()) h->tot_root_starts++;
     }
     std::vector<char> is_src(h->pool_slots, 0);
     for (int k = 0; k < nl; k++) is_src[src[k]] = 1;
@@ -899,6 +913,14 @@ int bslv_benson_lp_dims(const bslv_benson *h, int *M, int *N, int *rows_folded)
     if (M) *M = h->M;
     if (N) *N = h->N;
     if (rows_folded) *rows_folded = h->rows_folded;
+    return 0;
+}
+// LPs whose parent's tableau was not resident on this rank: started from the root tableau / from the nearest resident tableau
+int bslv_benson_start_stats(const bslv_benson *h, long *root_starts, long *nearest_starts)
+{
+    if (!h) return BSLV_E_ARG;
+    if (root_starts) *root_starts = h->tot_root_starts;
+    if (nearest_starts) *nearest_starts = h->tot_nearest_starts;
     return 0;
 }
 int bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots)

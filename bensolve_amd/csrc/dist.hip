@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <vector>
 #include <chrono>
+#include <string>
 
 using namespace bslv;
 
@@ -172,10 +173,23 @@ int bslv_benson_step_dist(bslv_benson *h, int max_batch_global, long *stats, dou
     std::vector<double> block((size_t)(cap + 1) * RL, 0.0), all((size_t)(cap + 1) * RL * world);
     int piv = 0, ls = 0;
     auto t1 = std::chrono::steady_clock::now();
-    if ((rc = bslv_benson_solve_local(h, block.data() + RL, &piv, &ls))) return rc;
-    block[0] = nl;
+    // A failure that only this rank sees (its tableau pool exhausted, a device error in its LPs) must not keep it out of the
+    // collective -- the others would wait in ncclAllGather for ever.  The header row of the block carries a status word: a
+    // failing rank sends an empty block with its error code, and every rank returns an error when any rank reports one.
+    const int rc_local = bslv_benson_solve_local(h, block.data() + RL, &piv, &ls);
+    std::string local_err = rc_local ? bslv_last_error() : "";
+    block[0] = rc_local ? 0 : nl;
+    block[1] = rc_local;
     auto t2 = std::chrono::steady_clock::now();
     if ((rc = bslv_dist_allgather(block.data(), all.data(), (cap + 1) * RL))) return rc;
+    for (int r = 0; r < world; r++) {
+        const int st_r = (int)all[(size_t)r * (cap + 1) * RL + 1];
+        if (st_r) {
+            if (r == rank) set_error("rank %d: %s", rank, local_err.c_str());
+            else set_error("rank %d reported error %d in its LP phase (its own message names the cause); this rank stops with it", r, st_r);
+            return r == rank ? rc_local : BSLV_E_STATE;
+        }
+    }
     std::vector<double> rec;
     rec.reserve((size_t)std::max(nt, 1) * RL);
     int total = 0;

@@ -38,6 +38,7 @@ static void usage(void)
 #include <arpa/inet.h>
 #include <netdb.h>
 #include <unistd.h>
+#include <poll.h>
 static int env_int(const char *k, int dflt) { const char *v = getenv(k); return v && *v ? atoi(v) : dflt; }
 static int dist_bootstrap(int *rank_out)
 {
@@ -56,6 +57,9 @@ static int dist_bootstrap(int *rank_out)
         sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons((unsigned short)port);
         if (ls < 0 || bind(ls, (struct sockaddr *)&sa, sizeof sa) || listen(ls, world)) { printf("rank 0: cannot listen on port %d\n", port); return -1; }
         for (int k = 1; k < world; k++) {
+            /* a peer that died before it connected (no GPU, bad LOCAL_RANK) must not leave rank 0 waiting for ever: two minutes */
+            struct pollfd pf; pf.fd = ls; pf.events = POLLIN; pf.revents = 0;
+            if (poll(&pf, 1, 120000) <= 0) { printf("rank 0: only %d of %d ranks asked for the communicator id within two minutes\n", k, world); close(ls); return -1; }
             int c = accept(ls, NULL, NULL);
             if (c < 0 || write(c, id, 128) != 128) { printf("rank 0: handing out the communicator id failed\n"); return -1; }
             close(c);

@@ -995,7 +995,16 @@ int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double 
     h->c0 = cost[0];
     int rc = 0;
     auto fail = [&](int code) { bslv_lpq_destroy(h); return code; };
-    if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
+    // BSLV_LP_CUMASK=<hex word>: the engine's stream may only use the CUs whose bit is set in the word (repeated over all CUs), e.g.
+    // 77777777 = three of every four.  For the pipelined driver: the tableau passes saturate HBM from fewer CUs than the chip
+    // has, and the small kernels of the cut phase, on their own stream, find free CUs instead of queueing behind them.
+    if (const char *cm = getenv("BSLV_LP_CUMASK")) {
+        const unsigned word = (unsigned)strtoul(cm, nullptr, 16);
+        unsigned mask[16];
+        for (int k = 0; k < 16; k++) mask[k] = word;
+        if (hipExtStreamCreateWithCUMask(&h->stream, 16, mask) != hipSuccess) { (void)hipGetLastError(); h->stream = nullptr; }
+    }
+    if (!h->stream && hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
 #define TRYF(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? BSLV_E_NOMEM : BSLV_E_NODEVICE); } } while (0)
     TRYF(hipMalloc(&L.T, (size_t)pool_slots * L.slotT * sizeof(double)));
     TRYF(hipMalloc(&L.beta, (size_t)pool_slots * L.Mp1p * sizeof(double)));

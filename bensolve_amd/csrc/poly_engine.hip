@@ -1664,11 +1664,12 @@ __device__ __forceinline__ void flags_block(const PolyView &P, const int2 *E, in
         if (threadIdx.x == 0) vbsum[b] = tot;
     }
 }
+// nv_dev (rounds queued ahead of the host): the element count is still on the device, as ne_dev
 __global__ __launch_bounds__(1024) void k_flags2(PolyView P, const int2 *E, int ne_ub, const int *ne_dev, int nbe, int nv0, const int *counters,
-                                                 unsigned char *eflag, int *ecount, Tri *ebsum, Tri *vbsum, ZMarks Z)
+                                                 unsigned char *eflag, int *ecount, Tri *ebsum, Tri *vbsum, ZMarks Z, const int *nv_dev = nullptr)
 {
     __shared__ Tri lds[16];
-    flags_block(P, E, ne_dev ? *ne_dev : ne_ub, nbe, (int)gridDim.x - nbe, nv0, counters, eflag, ecount, ebsum, vbsum, Z, (int)blockIdx.x, lds, false);
+    flags_block(P, E, ne_dev ? *ne_dev : ne_ub, nbe, (int)gridDim.x - nbe, nv_dev ? *nv_dev : nv0, counters, eflag, ecount, ebsum, vbsum, Z, (int)blockIdx.x, lds, false);
 }
 // emit pass.  Edge blocks: survivors -> Enew[0..nsurv), one new vertex per crossing edge (coordinates, flags,
 // incidence list, its edge to the PLUS end at Enew[nsurv + crossidx]).  Vertex blocks: MINUS elements leave,
@@ -2015,10 +2016,11 @@ struct K2V2 {
 };
 __device__ __forceinline__ void k2v2_sizes(const RState *st, int &S, int &go, int &nzero, int &nv0, int &ncross);
 __device__ void k2v2_check_members(const K2V2 &V, int vs, const int *s_mem, int nm, const int *members, int nzero);
+// (a device function: the kernel of the single-cut pipeline, k2_fused_t<false>, and the prune launch of a round, k_r2_k2, call it)
 template <bool V2>
-__global__ __launch_bounds__(K2T) void k2_fused_t(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
-                                                  int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg,
-                                                  const CutDev *cd, int *abort_flag, int *EP, Hp hn, int *counters_n, int *zlist_n, K2V2 V)
+__device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
+                              int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg,
+                              const CutDev *cd, int *abort_flag, int *EP, const Hp &hn, int *counters_n, int *zlist_n, const K2V2 &V)
 {
     extern __shared__ unsigned long long k2_dyn[];
     if (V2) {
@@ -2242,6 +2244,14 @@ __global__ __launch_bounds__(K2T) void k2_fused_t(PolyView P, int *members, int 
     }
 }
 
+
+template <bool V2>
+__global__ __launch_bounds__(K2T) void k2_fused_t(PolyView P, int *members, int nzero, int nv0, int ncross, int *fcount, int *flocal,
+                                                  int lds_words, int2 *E, int ebase, int *ne_dev, Tri *totals, Mail *mail, int seq, unsigned long long *dbg,
+                                                  const CutDev *cd, int *abort_flag, int *EP, Hp hn, int *counters_n, int *zlist_n, K2V2 V)
+{
+    k2_fused_body<V2>(P, members, nzero, nv0, ncross, fcount, flocal, lds_words, E, ebase, ne_dev, totals, mail, seq, dbg, cd, abort_flag, EP, hn, counters_n, zlist_n, V);
+}
 
 // the result of a prune (device memory: a write to host memory at the very end of the kernel kept the NEXT launch
 // waiting for the PCIe acknowledgement, 5-6 us per cut) normally reaches the host with the mailbox of the next round A;
@@ -2599,7 +2609,7 @@ __device__ void k2v2_check_members(const K2V2 &V, int vs, const int *s_mem, int 
 }
 __device__ __forceinline__ void k2v2_sizes(const RState *st, int &S, int &go, int &nzero, int &nv0, int &ncross)
 {
-    S = st->S; go = st->go; nzero = st->nzero; nv0 = st->nv; ncross = st->ncross;
+    S = st->S; go = st->go && !r2_halted(st); nzero = st->nzero; nv0 = st->nv; ncross = st->ncross;
 }
 
 
@@ -2613,6 +2623,9 @@ struct bslv_poly {
     RoundsBuf *rounds = nullptr;      // scratch of the multi-cut path
     Rounds2Buf *rounds2 = nullptr;    // scratch of the device-selected rounds inside a hot chunk (poly_rounds2_host.inc)
     bool rounds2_enabled = true;      // BSLV_NO_ROUNDS2=1 / bslv_poly_debug_set(h, 6, 0): hot chunks go through the single-cut pipeline
+    int r2_fuse = 0;                  // (default 0: measured fastest) 1: the classification of a round's new vertices rides in the launch of its prunes (extra workgroups); 2: and the last prune workgroup to finish writes the adjacent pairs (a ticket; measured slower); 0: three launches (BSLV_R2_FUSE / debug_set key 13)
+    bool r2_spec = true;              // rounds are queued one ahead of the host (BSLV_R2_SPEC=0 / debug_set key 12: the host reads every round's mailbox before it queues the next)
+    long r2_spec_void = 0;            // rounds that were queued ahead and found the device halted (bslv_poly_rounds2_stats)
     bool r2_mis = false;              // BSLV_R2_MIS=1 / debug_set key 11: rounds take a MAXIMAL independent set from a conflict matrix of the chunk (round 3; measured no faster on S-mid)
     int chunk_cuts = 512;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
     int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
@@ -2961,16 +2974,27 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     if (shard) {
         // this rank's pairs into a staging list, counts and pairs all-gathered (8 bytes per pair, carried as the bit pattern of a double)
         const int world = bslv_dist_world();
-        if ((size_t)tp.a > h->shardcap) { const size_t nc = std::max<size_t>((size_t)tp.a, std::max<size_t>(4096, h->shardcap * 2)); if ((rc = grow(&h->shard_e, 0, nc, s))) return rc; h->shardcap = nc; }
-        if (tp.a > 0)
-            hipLaunchKernelGGL(k_pair_emit_list, dim3(4096), dim3(PB), 0, s, h->members, nm, (const int *)h->nzlist, (const int *)(h->nzlist + h->nzcap), (const unsigned char *)h->pflag,
-                               (const Tri *)h->bsum, h->shard_e, 0, (int *)nullptr);
-        HIP_TRY(hipGetLastError());
         std::vector<double> cnt_all((size_t)world), mine((size_t)std::max(tp.a, 1));
-        if (tp.a > 0) HIP_TRY(hipMemcpyAsync(mine.data(), h->shard_e, (size_t)tp.a * sizeof(int2), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        const double my_cnt = (double)tp.a;
+        // what only this rank does before the exchange; a failure here still enters the all-gather, with a negative count as the
+        // status word, so that the other ranks return an error instead of waiting for ever
+        auto local = [&]() -> int {
+            if ((size_t)tp.a > h->shardcap) { const size_t nc = std::max<size_t>((size_t)tp.a, std::max<size_t>(4096, h->shardcap * 2)); if ((rc = grow(&h->shard_e, 0, nc, s))) return rc; h->shardcap = nc; }
+            if (tp.a > 0)
+                hipLaunchKernelGGL(k_pair_emit_list, dim3(4096), dim3(PB), 0, s, h->members, nm, (const int *)h->nzlist, (const int *)(h->nzlist + h->nzcap), (const unsigned char *)h->pflag,
+                                   (const Tri *)h->bsum, h->shard_e, 0, (int *)nullptr);
+            HIP_TRY(hipGetLastError());
+            if (tp.a > 0) HIP_TRY(hipMemcpyAsync(mine.data(), h->shard_e, (size_t)tp.a * sizeof(int2), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            return 0;
+        };
+        const int rc_local = local();
+        const double my_cnt = rc_local ? -(double)rc_local : (double)tp.a;
         if ((rc = bslv_dist_allgather(&my_cnt, cnt_all.data(), 1))) return rc;
+        for (int r = 0; r < world; r++)
+            if (cnt_all[r] < 0) {
+                if (r != bslv_dist_rank()) set_error("rank %d reported error %d in its share of a sharded adjacency prune; this rank stops with it", r, (int)-cnt_all[r]);
+                return r == bslv_dist_rank() ? rc_local : BSLV_E_STATE;
+            }
         long long total = 0; int maxc = 0;
         for (int r = 0; r < world; r++) { total += (long long)cnt_all[r]; maxc = std::max(maxc, (int)cnt_all[r]); }
         if (total > 0) {
@@ -3429,7 +3453,8 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     // k2_fused keeps the local incidence bit matrix in LDS: ask for most of the CU's 160 KB, settle for 48 KB
     h->k2_lds = 128 * 1024;
     if (hipFuncSetAttribute((const void *)k2_fused_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k2_fused_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess) {
+        hipFuncSetAttribute((const void *)k2_fused_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_r2_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k2_lds) != hipSuccess) {
         (void)hipGetLastError();
         h->k2_lds = 48 * 1024;
     }
@@ -3438,6 +3463,8 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
     if (getenv("BSLV_NO_ROUNDS2")) h->rounds2_enabled = false;
     if (const char *e = getenv("BSLV_R2_MIS")) h->r2_mis = atoi(e) != 0;
+    if (const char *e = getenv("BSLV_R2_SPEC")) h->r2_spec = atoi(e) != 0;
+    if (const char *e = getenv("BSLV_R2_FUSE")) h->r2_fuse = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("BSLV_CHUNK_CUTS")) h->chunk_cuts = std::min(4096, std::max(32, atoi(e)));
     if (const char *e = getenv("BSLV_R2_MIN_CUTS")) h->r2_min_cuts = std::max(-1, atoi(e));
     if (const char *e = getenv("BSLV_R2_RULE")) h->r2_rule = atoi(e) ? 1 : 0;
@@ -3930,6 +3957,8 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 6: h->rounds2_enabled = value != 0; return 0;                  /* device-selected rounds of independent cuts inside a hot chunk */
     case 7: h->chunk_cuts = (int)std::min(4096L, std::max(32L, value)); return 0;    /* cuts classified and applied together */
     case 10: h->shard_min = (int)std::max(2L, value); return 0;           /* multi-GPU: facets from this size on have their pair space dealt to the ranks */
+    case 13: h->r2_fuse = (int)std::min(2L, std::max(0L, value)); return 0;                           /* one launch for a round's prunes + classification + pair emission (1) / three (0) */
+    case 12: h->r2_spec = value != 0; return 0;                           /* rounds queued one ahead of the host (1) / mailbox read before every round (0) */
     case 11: h->r2_mis = value != 0; return 0;                            /* rounds: maximal independent set from the conflict matrix (1) / local minima of one order (0) */
     case 9: g_k1_mfma = value != 0; return 0;                            /* incidence kernel K1 on the matrix pipe from 16 halfspaces on (1) or the scalar kernel (0, default); process-wide */
     case 8: h->r2_min_cuts = (int)std::max(-1L, value); return 0;        /* rounds go on while they average at least this many cuts (0: until every round holds one cut, -1: always) */

@@ -267,6 +267,9 @@ int  bslv_benson_last_local(bslv_benson *h, int max_out, int *src, int *pivots, 
 /* tableau pool: out[0] free slots, [1] resident warm-start sources, [2] held by a batch in flight, [3] pool size */
 int  bslv_benson_pool_stats(bslv_benson *h, long out[4]);
 int  bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivots);
+/* warm starts: LPs whose parent's tableau was not resident on this rank (evicted, or solved on another rank) and that started
+ * from the root tableau / from the resident tableau whose own vertex is nearest */
+int  bslv_benson_start_stats(const bslv_benson *h, long *root_starts, long *nearest_starts);
 /* size of the P2 model after the driver's presolve (rows of A with a single non-zero become column bounds and leave the
  * LP; the hypercube rows of S-degenerate, ex/example10.m:21-24): M x N of init_P2 (bslv_algs.c:574-664) minus the folded rows */
 int  bslv_benson_lp_dims(const bslv_benson *h, int *M, int *N, int *rows_folded);

@@ -124,3 +124,58 @@ def test_two_ranks_through_the_c_step(args, batch):
         assert out2[0]["sharded"] == 0
         for k in ("pu", "pi", "ps", "E", "I", "X", "Y", "du", "DE"):
             assert np.array_equal(d0[k], out2[0][k]), "sharded prune differs from the replicated prune in " + k
+
+
+def _steps_worker(rank, world, port, args, batch, steps, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dist_init_callback(dist)
+    eng = BensonEngine(synth.covering_vlp(*args), eps=1e-7, pool_slots=4 * batch + 64)
+    assert eng.start() == 0
+    lps = piv = cuts = 0
+    r0 = None
+    for k in range(steps):
+        if k == steps // 2:                       # (the first half is the ramp: few vertices, cold tableaux)
+            r0 = (eng.poly_call("rounds_run"), cuts, lps, piv)
+        s = eng.step(batch)
+        lps += s["lps"]; piv += s["pivots"]; cuts += s["cuts"]
+    out[rank] = dict(lps=lps - r0[2], local_pivots=piv - r0[3], cuts=cuts - r0[1], passes=eng.poly_call("rounds_run") - r0[0], starts=eng.start_stats())
+    eng.close()
+    dist_finalize()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_keep_their_warm_starts():
+    """a two-rank rehearsal showed 73 pivots per LP against 5 with one rank -- vertices dealt to the rank that does not
+    hold their parent's tableau started from the root tableau.  They now start from the nearest resident tableau of the rank that
+    gets them, and the dealing rule keeps families with their owner: two ranks must not need more than twice the pivots per LP of
+    one rank on the same global batch, nor fewer cuts per pass (the cut phase is replicated)."""
+    import torch.multiprocessing as mp
+    args, batch, steps = (300, 150, 4, 11), 512, 24
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_steps_worker, args=(2, port, args, batch, steps, out), nprocs=2, join=True)
+    two_lps = out[0]["lps"]
+    two_piv = out[0]["local_pivots"] + out[1]["local_pivots"]
+    assert out[0]["lps"] == out[1]["lps"] and out[0]["cuts"] == out[1]["cuts"] and out[0]["passes"] == out[1]["passes"]
+    eng = BensonEngine(synth.covering_vlp(*args), eps=1e-7, pool_slots=4 * batch + 64)
+    assert eng.start() == 0
+    lps = piv = cuts = 0
+    for k in range(steps):
+        if k == steps // 2:
+            r0 = (eng.poly_call("rounds_run"), cuts, lps, piv)
+        st = eng.step(batch)
+        lps += st["lps"]; piv += st["pivots"]; cuts += st["cuts"]
+    one = dict(lps=lps - r0[2], piv=piv - r0[3], cuts=cuts - r0[1], passes=eng.poly_call("rounds_run") - r0[0])
+    eng.close()
+    assert one["lps"] > 2000 and two_lps > 2000
+    ppl1, ppl2 = one["piv"] / one["lps"], two_piv / two_lps
+    cpp1, cpp2 = one["cuts"] / max(one["passes"], 1), out[0]["cuts"] / max(out[0]["passes"], 1)
+    print("pivots per LP: one rank %.2f, two ranks %.2f | cuts per pass %.2f / %.2f | starts of the two ranks: %s %s" % (ppl1, ppl2, cpp1, cpp2, out[0]["starts"], out[1]["starts"]))
+    assert ppl2 <= 2.0 * ppl1 + 1.0, (ppl1, ppl2)
+    assert cpp2 >= 0.8 * cpp1, (cpp1, cpp2)

@@ -13,7 +13,7 @@ from test_poly_gpu import assert_slotwise_equal
 
 pytestmark = pytest.mark.gpu
 
-HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS", "BSLV_R2_MIS"]
+HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS", "BSLV_R2_MIS", "BSLV_R2_SPEC", "BSLV_R2_FUSE"]
 MODES = {
     "default": {},
     "no_spec": {"BSLV_NO_SPEC": "1"},
@@ -131,6 +131,10 @@ R2_MODES = {
     "rounds, every prune through the multi-kernel path": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_K2_LDS": "64"},
     "rounds without speculation in the tail": {"BSLV_NO_SPEC": "1"},
     "rounds that take a maximal independent set from a conflict matrix": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "1"},
+    "rounds read by the host one at a time (none queued ahead)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_SPEC": "0"},
+    "prune, classification and pair emission in three launches": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FUSE": "0"},
+    "three launches, every prune through the multi-kernel path": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FUSE": "0", "BSLV_K2_LDS": "64"},
+    "rounds queued ahead, short capacities (declined rounds)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_CHUNK_CUTS": "96"},
     "conflict matrix, chunks of 1024": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "1", "BSLV_CHUNK_CUTS": "1024"},
 }
 
