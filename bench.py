@@ -229,7 +229,7 @@ def main():
     # are selected on vectors, then applied together).  Unit = one (LP, pass); algorithmic bytes per unit = one read + one
     # write of the eliminated tableau, 16*(m+r+1)*(n+2) -- SURVEY 8d K3's figure, which the reference algorithm pays per PIVOT.
     dims = eng.lp_dims()                 # (rows of A that were single-variable bounds are not in the LP)
-    m_lp = dims["M"] - q - r - 1
+    m_lp = dims["M"] - dims["rows_folded"] - q - r - 1     # rows of A in the TABLEAU (the LP layer folds rows with one non-zero into column bounds)
     alg_bytes_per_pass = 16.0 * (m_lp + r + 1) * (n + 2)
     launches = max(lockstep, 1)
     achieved = (passes * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
@@ -326,7 +326,7 @@ def main():
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s (q=%d, n=%d, m=%d dense covering VLP, seed per SURVEY 8d)" % (args.workload, q, n, m),
-                       "lp_rows_cols": [dims["M"], dims["N"]], "rows_folded_by_presolve": dims["rows_folded"], "batch_per_gpu": B, "global_batch": B * world,
+                       "lp_rows_cols": [dims["M"] - dims["rows_folded"], dims["N"]], "rows_folded_by_presolve": dims["rows_folded"], "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "vertex batch sharded over %d GPU(s), one all-gather of cut records per step (in the library), cut application replicated" % world,
                        "transport": transport,
                        "lp_poly_overlap": pipe is not None,

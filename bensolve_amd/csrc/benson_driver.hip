@@ -132,35 +132,25 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
         return BSLV_E_ARG;
     }
     bslv_benson *h = new bslv_benson();
-    // Presolve: a row of A with a single non-zero is a bound on that column (the hypercube rows of S-degenerate, SURVEY 8d;
-    // ex/example10.m:21-24 states its box the same way).  It is folded into the column's bounds and dropped from the LP: the
-    // LP loses a row, and the column becomes boxed, which is what the bound flipping ratio test of the LP engine works on.
-    // Only y* (duals of the q objective rows) and y leave the LP layer in phase 2, so no dual of a folded row is ever read.
+    // (Singleton rows of A -- the hypercube rows of S-degenerate, ex/example10.m:21-24 -- are folded into column bounds by the LP
+    // layer itself since round 3, bslv_lpq_create: every index below is an index of the model as the reference builds it.)
     auto vlp_bounds = [hom](char t, double lb, double ub, double *lo, double *up) {
         if (hom) bounds_of(t == 'd' ? 's' : t, 0.0, 0.0, lo, up); else bounds_of(t, lb, ub, lo, up);
     };
     std::vector<double> clo(n), cup(n);
     for (int j = 0; j < n; j++) vlp_bounds(ctype[j], clb ? clb[j] : 0, cub ? cub[j] : 0, &clo[j], &cup[j]);
-    std::vector<int> keep;
-    keep.reserve(m);
-    for (int i = 0; i < m; i++) {
-        int nz = 0, jj = -1;
-        for (int j = 0; j < n && nz < 2; j++) if (A[(size_t)i * n + j] != 0.0) { nz++; jj = j; }
-        double lo_i, up_i;
-        vlp_bounds(rtype[i], rlb ? rlb[i] : 0, rub ? rub[i] : 0, &lo_i, &up_i);
-        if (nz == 1 && !(flags & BSLV_BENSON_PREIMAGES) && !getenv("BSLV_NO_PRESOLVE")) {
-            const double a = A[(size_t)i * n + jj];
-            double lo = a > 0 ? lo_i / a : up_i / a, up = a > 0 ? up_i / a : lo_i / a;
-            lo = std::max(lo, clo[jj]); up = std::min(up, cup[jj]);
-            if (lo <= up) { clo[jj] = lo; cup[jj] = up; continue; }        // (an empty box stays a row: the LP reports it)
+    std::vector<int> keep(m);
+    for (int i = 0; i < m; i++) keep[i] = i;
+    int singletons = 0;                                   // (only to size the pool: rows with one non-zero leave the tableau)
+    if (!getenv("BSLV_NO_PRESOLVE"))
+        for (int i = 0; i < m; i++) {
+            int nz = 0;
+            for (int j = 0; j < n && nz < 2; j++) if (A[(size_t)i * n + j] != 0.0) nz++;
+            singletons += nz == 1;
         }
-        keep.push_back(i);
-    }
+    singletons = std::min(singletons, m - 1);
     h->want_primg = (flags & BSLV_BENSON_PREIMAGES) != 0;
     h->m_orig = m;
-    h->rows_folded = m - (int)keep.size();
-    if (keep.empty()) { keep.push_back(0); h->rows_folded = m - 1; }      // (the LP layer wants at least one row of A)
-    m = (int)keep.size();
     h->m = m; h->n = n; h->q = q; h->r = r; h->eps = eps;
     h->R.assign(R, R + (size_t)q * r);
     h->c.assign(c, c + q);
@@ -196,7 +186,8 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
             const size_t ld = ((size_t)N + 2 + 1) & ~(size_t)1;
-            const size_t slot = ((size_t)M + 2) * ld * sizeof(double) + ((size_t)M * 2 + (size_t)N * 4 + ld) * 8;
+            const size_t Mt = (size_t)(M - singletons);         // rows of the tableau
+            const size_t slot = (Mt + 2) * ld * sizeof(double) + (Mt * 2 + (size_t)N * 4 + ld) * 8;
             const size_t fit = (size_t)(0.7 * (double)fr) / std::max<size_t>(slot, 1);
             if ((size_t)pool_slots > fit) {
                 if (fit < 8) { set_error("bslv_benson_create: a tableau of %zu MB does not fit 8 times into the %zu MB of free device memory", slot >> 20, fr >> 20); bslv_benson_destroy(h); return BSLV_E_CAPACITY; }
@@ -207,6 +198,7 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
     }
     int rc = bslv_lpq_create(&h->lp, M, N, L.data(), lo.data(), up.data(), cost.data(), m + q, r, pool_slots);
     if (rc) { bslv_benson_destroy(h); return rc; }
+    h->rows_folded = bslv_lpq_rows_folded(h->lp);
     rc = bslv_poly_create(&h->poly, q, 1 /* lowerV2upperH */, c);
     if (rc) { bslv_benson_destroy(h); return rc; }
     h->pool_slots = pool_slots;
@@ -910,7 +902,7 @@ int bslv_benson_set_preimage_p(bslv_benson *h, int element, const double *x)
 int bslv_benson_lp_dims(const bslv_benson *h, int *M, int *N, int *rows_folded)
 {
     if (!h) return BSLV_E_ARG;
-    if (M) *M = h->M;
+    if (M) *M = h->M;                                // (rows of the model as given: what every index at the LP boundary refers to; the tableau has rows_folded fewer)
     if (N) *N = h->N;
     if (rows_folded) *rows_folded = h->rows_folded;
     return 0;

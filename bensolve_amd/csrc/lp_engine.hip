@@ -865,6 +865,21 @@ struct bslv_lpq {
     double last_update_ms = 0, last_total_ms = 0;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evpool;
+    // PRESOLVE at the boundary (round 3): a row of A with a single non-zero outside the per-LP range is a bound on that column
+    // (the hypercube rows `d 0 1` of ex/example10.m:21-24 and of S-degenerate); it is folded into the column's bounds and leaves the
+    // tableau.  The callers keep the model they handed over (GLPK's, bslv_lp.c:60-70,219-308): every index that crosses the
+    // boundary is an index of THAT model, the primal value of a folded row is a_ij x_j, and its dual is the column's reduced cost
+    // over a_ij whenever the bound the column sits on is the row's and not its own.
+    struct Presolve {
+        int M0 = 0, N0 = 0, nfold = 0;                 // the model as given; rows folded
+        std::vector<int> row_in;                       // given row -> row of the engine's model, or -1 (folded)
+        std::vector<int> fold_col;                     // given row -> column it bounds (folded rows)
+        std::vector<double> fold_a;                    //              its coefficient
+        std::vector<double> lb0, ub0;                  // bounds as given (M0 + N0), kept for set_bounds
+        std::vector<int> lo_src, up_src;               // per column: the folded row whose bound is the tighter one, or -1 (its own)
+        std::vector<double> clo, cup;                  // per column: folded bounds
+        int map_var(int v) const { return v < M0 ? row_in[v] : (M0 - nfold) + (v - M0); }
+    } ps;
 };
 
 static int ensure_batch(bslv_lpq *h, int B)
@@ -971,8 +986,8 @@ int bslv_device_info(char *name, int name_len, int *cus, size_t *mem_bytes)
     return 0;
 }
 
-int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double *lb, const double *ub,
-                    const double *cost, int var_first, int var_cnt, int pool_slots)
+static int raw_create(bslv_lpq **out, int M, int N, const double *A, const double *lb, const double *ub,
+                      const double *cost, int var_first, int var_cnt, int pool_slots)
 {
     if (!out || M < 1 || N < 1 || !A || !lb || !ub || !cost || pool_slots < 1 || var_cnt < 0 ||
         (var_cnt > 0 && (var_first < 0 || var_first + var_cnt > M + N))) {
@@ -1065,10 +1080,86 @@ size_t bslv_lpq_slot_bytes(const bslv_lpq *h)
     return (L.slotT + L.Mp1p + L.ld) * sizeof(double) + (size_t)(2 * (L.M + L.N) + L.N) * sizeof(int);
 }
 
+// bounds of the engine's model from the bounds of the model as given: the folded rows tighten their columns
+static void fold_bounds(bslv_lpq *h, const double *lb, const double *ub, std::vector<double> &lo, std::vector<double> &up)
+{
+    bslv_lpq::Presolve &P = h->ps;
+    const int M0 = P.M0, N0 = P.N0, Mi = M0 - P.nfold;
+    P.lb0.assign(lb, lb + M0 + N0); P.ub0.assign(ub, ub + M0 + N0);
+    lo.assign((size_t)Mi + N0, 0.0); up.assign((size_t)Mi + N0, 0.0);
+    P.clo.assign(lb + M0, lb + M0 + N0); P.cup.assign(ub + M0, ub + M0 + N0);
+    P.lo_src.assign(N0, -1); P.up_src.assign(N0, -1);
+    for (int i = 0; i < M0; i++) {
+        if (P.row_in[i] >= 0) { lo[P.row_in[i]] = lb[i]; up[P.row_in[i]] = ub[i]; continue; }
+        const int j = P.fold_col[i];
+        const double a = P.fold_a[i];
+        const double l = a > 0 ? lb[i] / a : ub[i] / a, u = a > 0 ? ub[i] / a : lb[i] / a;
+        if (l > P.clo[j]) { P.clo[j] = l; P.lo_src[j] = i; }
+        if (u < P.cup[j]) { P.cup[j] = u; P.up_src[j] = i; }
+    }
+    for (int j = 0; j < N0; j++) { lo[Mi + j] = P.clo[j]; up[Mi + j] = P.cup[j]; }
+}
 int bslv_lpq_set_bounds(bslv_lpq *h, const double *lb, const double *ub)
 {
     if (!h || !lb || !ub) { set_error("bslv_lpq_set_bounds: bad argument"); return BSLV_E_ARG; }
-    return upload_bounds(h, lb, ub);
+    if (h->ps.nfold == 0) { h->ps.lb0.assign(lb, lb + h->ps.M0 + h->ps.N0); h->ps.ub0.assign(ub, ub + h->ps.M0 + h->ps.N0); return upload_bounds(h, lb, ub); }
+    std::vector<double> lo, up;
+    fold_bounds(h, lb, ub, lo, up);
+    return upload_bounds(h, lo.data(), up.data());
+}
+int bslv_lpq_rows_folded(const bslv_lpq *h) { return h ? h->ps.nfold : 0; }
+
+int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double *lb, const double *ub,
+                    const double *cost, int var_first, int var_cnt, int pool_slots)
+{
+    if (!out || M < 1 || N < 1 || !A || !lb || !ub || !cost || pool_slots < 1 || var_cnt < 0 ||
+        (var_cnt > 0 && (var_first < 0 || var_first + var_cnt > M + N))) {
+        set_error("bslv_lpq_create: bad argument");
+        return BSLV_E_ARG;
+    }
+    bslv_lpq::Presolve P;
+    P.M0 = M; P.N0 = N;
+    P.row_in.assign(M, 0); P.fold_col.assign(M, -1); P.fold_a.assign(M, 0.0);
+    std::vector<double> clo(lb + M, lb + M + N), cup(ub + M, ub + M + N);
+    const bool off = getenv("BSLV_NO_PRESOLVE") != nullptr;
+    int kept = 0;
+    for (int i = 0; i < M; i++) {
+        bool fold = false;
+        const bool per_lp = var_cnt > 0 && i >= var_first && i < var_first + var_cnt;
+        if (!off && !per_lp && M - P.nfold > 1) {
+            int nz = 0, jj = -1;
+            const double *row = A + (size_t)i * N;
+            for (int j = 0; j < N && nz < 2; j++) if (row[j] != 0.0) { nz++; jj = j; }
+            if (nz == 1) {
+                const double a = row[jj];
+                const double l = std::max(clo[jj], a > 0 ? lb[i] / a : ub[i] / a), u = std::min(cup[jj], a > 0 ? ub[i] / a : lb[i] / a);
+                if (l <= u) { fold = true; clo[jj] = l; cup[jj] = u; P.fold_col[i] = jj; P.fold_a[i] = a; }      // (an empty box stays a row: the LP reports it)
+            }
+        }
+        if (fold) { P.row_in[i] = -1; P.nfold++; } else P.row_in[i] = kept++;
+    }
+    if (P.nfold == 0) {
+        const int rc = raw_create(out, M, N, A, lb, ub, cost, var_first, var_cnt, pool_slots);
+        if (rc) return rc;
+        (*out)->ps = P;
+        (*out)->ps.lb0.assign(lb, lb + M + N); (*out)->ps.ub0.assign(ub, ub + M + N);
+        return 0;
+    }
+    const int Mi = M - P.nfold;
+    std::vector<double> Ai((size_t)Mi * N);
+    for (int i = 0; i < M; i++) if (P.row_in[i] >= 0) memcpy(&Ai[(size_t)P.row_in[i] * N], A + (size_t)i * N, (size_t)N * sizeof(double));
+    // the per-LP range keeps its place among the rows that stay (no row inside it is folded); a range over columns moves with them
+    int vf = var_first;
+    if (var_cnt > 0) vf = var_first < M ? P.row_in[var_first] : Mi + (var_first - M);
+    std::vector<double> lo0((size_t)Mi + N, 0.0), up0((size_t)Mi + N, 0.0);
+    for (int i = 0; i < M; i++) if (P.row_in[i] >= 0) { lo0[P.row_in[i]] = lb[i]; up0[P.row_in[i]] = ub[i]; }
+    for (int j = 0; j < N; j++) { lo0[Mi + j] = clo[j]; up0[Mi + j] = cup[j]; }
+    const int rc = raw_create(out, Mi, N, Ai.data(), lo0.data(), up0.data(), cost, vf, var_cnt, pool_slots);
+    if (rc) return rc;
+    (*out)->ps = P;
+    std::vector<double> lo, up;
+    fold_bounds(*out, lb, ub, lo, up);                    // (fills lo_src / up_src and the record of the bounds as given)
+    return 0;
 }
 
 int bslv_lpq_set_profile(bslv_lpq *h, int on)
@@ -1105,7 +1196,11 @@ int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, con
 int bslv_lpq_solve_batch_obj(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo, const double *vup,
                              int cost_first, int cost_cnt, const double *costs, int *status, int *iters)
 {
-    if (!h || cost_cnt < 1 || cost_first < 0 || cost_first + cost_cnt > h->L.M + h->L.N || !costs) { set_error("bslv_lpq_solve_batch_obj: bad argument"); return BSLV_E_ARG; }
+    if (!h || cost_cnt < 1 || cost_first < 0 || cost_first + cost_cnt > h->ps.M0 + h->ps.N0 || !costs) { set_error("bslv_lpq_solve_batch_obj: bad argument"); return BSLV_E_ARG; }
+    if (h->ps.nfold) {      // indices of the model as given -> the engine's (a cost on a folded row would be a cost on its column: not asked for by any caller)
+        for (int t = 0; t < cost_cnt; t++) if (h->ps.map_var(cost_first + t) != h->ps.map_var(cost_first) + t) { set_error("bslv_lpq_solve_batch_obj: the cost range covers rows the presolve folded into column bounds"); return BSLV_E_ARG; }
+        cost_first = h->ps.map_var(cost_first);
+    }
     for (size_t j = 0; j < h->cost.size(); j++) if (h->cost[j] != 0.0) { set_error("bslv_lpq_solve_batch_obj: the engine was created with a non-zero cost vector"); return BSLV_E_STATE; }
     return solve_batch_impl(h, B, src, dst, vlo, vup, cost_first, cost_cnt, costs, status, iters);
 }
@@ -1284,8 +1379,65 @@ static int get_common(bslv_lpq *h, int B, const int *slot, int first, int cnt, i
     return 0;
 }
 
-int bslv_lpq_get_primal(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out) { return get_common(h, B, slot, first, cnt, 0, out); }
-int bslv_lpq_get_dual(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out) { return get_common(h, B, slot, first, cnt, 1, out); }
+// values of the variables first .. first + cnt - 1 OF THE MODEL AS GIVEN.  A range without folded rows is one call into the
+// engine; otherwise the folded rows are rebuilt from their columns: primal a_ij x_j; dual d_j / a_ij when the column sits on the
+// bound the row gave it (the column's own reduced cost is then zero: it would be basic in the model as given), else 0.
+static int get_mapped(bslv_lpq *h, int B, const int *slot, int first, int cnt, int what, double *out)
+{
+    if (!h) { set_error("bslv_lpq_get: bad argument"); return BSLV_E_ARG; }
+    const bslv_lpq::Presolve &P = h->ps;
+    if (first < 0 || cnt < 0 || first + cnt > P.M0 + P.N0) { set_error("bslv_lpq_get: bad argument"); return BSLV_E_ARG; }
+    if (P.nfold == 0) return get_common(h, B, slot, first, cnt, what, out);
+    if (B == 0 || cnt == 0) return 0;
+    bool plain = true;
+    for (int t = 0; t < cnt && plain; t++) { const int v = first + t; if (v < P.M0 && P.row_in[v] < 0) plain = false; }
+    // (columns whose bound comes from a folded row need the split of their reduced cost as well)
+    if (plain && what == 1) for (int t = 0; t < cnt && plain; t++) { const int v = first + t; if (v >= P.M0 && (P.lo_src[v - P.M0] >= 0 || P.up_src[v - P.M0] >= 0)) plain = false; }
+    if (plain) {
+        // contiguous in the engine's model too: rows keep their order, columns follow the rows that stay
+        const int f2 = P.map_var(first);
+        bool contiguous = true;
+        for (int t = 0; t < cnt && contiguous; t++) if (P.map_var(first + t) != f2 + t) contiguous = false;
+        if (contiguous) return get_common(h, B, slot, f2, cnt, what, out);
+    }
+    const int Mi = P.M0 - P.nfold, NV = Mi + P.N0;
+    std::vector<double> prim((size_t)B * NV), dual;
+    int rc;
+    if ((rc = get_common(h, B, slot, 0, NV, 0, prim.data()))) return rc;
+    if (what == 1) { dual.resize((size_t)B * NV); if ((rc = get_common(h, B, slot, 0, NV, 1, dual.data()))) return rc; }
+    for (int b = 0; b < B; b++) {
+        const double *x = &prim[(size_t)b * NV], *d = what == 1 ? &dual[(size_t)b * NV] : nullptr;
+        // which bound a column sits on: the nearer one (a basic column has d = 0 and the answer does not matter)
+        auto on_row_bound = [&](int j) -> int {            // folded row whose bound column j sits on, or -1
+            if (!(d[Mi + j] != 0.0)) return -1;
+            const double xl = std::fabs(x[Mi + j] - P.clo[j]), xu = std::fabs(x[Mi + j] - P.cup[j]);
+            const bool at_lo = !(xu < xl);
+            const int src = at_lo ? P.lo_src[j] : P.up_src[j];
+            if (src < 0) return -1;
+            // (the row's bound and the column's own may coincide: then the column keeps the reduced cost -- either split is a dual solution)
+            const double own = at_lo ? P.lb0[P.M0 + j] : P.ub0[P.M0 + j], folded = at_lo ? P.clo[j] : P.cup[j];
+            return own == folded ? -1 : src;
+        };
+        for (int t = 0; t < cnt; t++) {
+            const int v = first + t;
+            double val;
+            if (v < P.M0 && P.row_in[v] >= 0) val = what == 0 ? x[P.row_in[v]] : d[P.row_in[v]];
+            else if (v < P.M0) {
+                const int j = P.fold_col[v];
+                if (what == 0) val = P.fold_a[v] * x[Mi + j];
+                else val = on_row_bound(j) == v ? d[Mi + j] / P.fold_a[v] : 0.0;
+            } else {
+                const int j = v - P.M0;
+                if (what == 0) val = x[Mi + j];
+                else val = on_row_bound(j) >= 0 ? 0.0 : d[Mi + j];
+            }
+            out[(size_t)b * cnt + t] = val;
+        }
+    }
+    return 0;
+}
+int bslv_lpq_get_primal(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out) { return get_mapped(h, B, slot, first, cnt, 0, out); }
+int bslv_lpq_get_dual(bslv_lpq *h, int B, const int *slot, int first, int cnt, double *out) { return get_mapped(h, B, slot, first, cnt, 1, out); }
 
 int bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out)
 {

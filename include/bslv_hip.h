@@ -67,6 +67,11 @@ int  bslv_lpq_create(bslv_lpq **out, int M, int N,
                      const double *cost /* N+1: cost[0] = constant shift (bslv_lp.h:33) */,
                      int var_first, int var_cnt, int pool_slots);
 void bslv_lpq_destroy(bslv_lpq *h);
+/* PRESOLVE at this boundary: a row of A with a single non-zero outside the per-LP range is a bound on its column (the rows `d 0 1`
+ * over free columns of ex/example10.m:21-24); it is folded into the column's bounds and leaves the tableau.  Every index of this
+ * interface stays an index of the model AS GIVEN (GLPK's, bslv_lp.c:60-70): get_primal of a folded row returns a_ij x_j, get_dual
+ * the column's reduced cost over a_ij when the column sits on the bound that row gave it.  BSLV_NO_PRESOLVE=1 switches it off. */
+int  bslv_lpq_rows_folded(const bslv_lpq *h);
 int  bslv_lpq_pool_slots(const bslv_lpq *h);
 size_t bslv_lpq_slot_bytes(const bslv_lpq *h);
 /* replace the shared bounds (lp_set_rows / lp_set_cols, bslv_lp.c:112-134) */
@@ -270,8 +275,9 @@ int  bslv_benson_totals(const bslv_benson *h, long *lps, long *cuts, long *pivot
 /* warm starts: LPs whose parent's tableau was not resident on this rank (evicted, or solved on another rank) and that started
  * from the root tableau / from the resident tableau whose own vertex is nearest */
 int  bslv_benson_start_stats(const bslv_benson *h, long *root_starts, long *nearest_starts);
-/* size of the P2 model after the driver's presolve (rows of A with a single non-zero become column bounds and leave the
- * LP; the hypercube rows of S-degenerate, ex/example10.m:21-24): M x N of init_P2 (bslv_algs.c:574-664) minus the folded rows */
+/* size of the P2 model: M x N of init_P2 (bslv_algs.c:574-664), the model every index at the LP boundary refers to;
+ * rows_folded of its rows (rows of A with a single non-zero: the hypercube rows of S-degenerate, ex/example10.m:21-24) were
+ * turned into column bounds by the LP layer's presolve (bslv_lpq_create), so the tableau has M - rows_folded rows */
 int  bslv_benson_lp_dims(const bslv_benson *h, int *M, int *N, int *rows_folded);
 bslv_poly *bslv_benson_poly(bslv_benson *h);
 bslv_lpq  *bslv_benson_lp(bslv_benson *h);

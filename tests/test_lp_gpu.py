@@ -372,3 +372,90 @@ def test_extended_selection_by_switch_gives_the_same_optima():
         eng.close()
     np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-9, atol=1e-9)
     _check_identities(model, V, *res[1])
+
+
+def test_lp_layer_presolve_solves_s_degenerate_as_stated():
+    """the LP of BASELINE configs[4] AS STATED -- 4021 x 2011, the hypercube written as 2000 rows `d 0 1` over free
+    columns (ex/example10.m:21-24) -- went through the LP engine with status UNDEFINED after 3e5 pivots; the presolve that made
+    it solvable sat in the Benson driver.  It now sits behind bslv_lpq_create: the model is handed over as the reference would
+    hand it to GLPK (bslv_lp.c:60-70), without synth.fold_singleton_rows, and the optimal values equal HiGHS'."""
+    import ctypes
+    prob = synth.CONFIGS["S-degenerate"]()
+    model = P2Model(prob)                                  # every row of A in the model
+    assert model.M == prob["m"] + 2 * prob["q"] + 1
+    rng = np.random.default_rng(11)
+    n, q, B = prob["n"], prob["q"], 4
+    V = rng.random((B, n)) @ prob["P"].T + rng.normal(scale=2.0, size=(B, q))
+    ub = model.ub_for(V)
+    eng = LpEngine.from_model(model, pool_slots=B + 1)
+    eng.lib.bslv_lpq_rows_folded.argtypes = [ctypes.c_void_p]
+    assert eng.lib.bslv_lpq_rows_folded(eng.h) == 2000
+    eng.reset_slot(0)
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+    assert st[0] == 4 and it[0] < 500, (st, it)
+    src = np.zeros(B, np.int32)
+    dst = np.arange(1, B + 1, dtype=np.int32)
+    st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+    assert np.all(st == 4)
+    obj = eng.obj(dst)
+    # the folded rows still answer: their primal value is the column's (a = 1), within the row's bounds
+    rows = eng.primal(dst, 0, 2000)
+    cols = eng.primal(dst, model.M, 2000)
+    eng.close()
+    np.testing.assert_allclose(rows, cols, rtol=0, atol=0)
+    assert rows.min() >= -1e-9 and rows.max() <= 1 + 1e-9
+    ref = np.array([_p2_highs(prob, V[b]) for b in range(B)])
+    np.testing.assert_allclose(obj, ref, rtol=1e-7, atol=1e-7)
+
+
+def test_presolve_keeps_the_model_of_the_caller_primal_and_dual():
+    """Rows with one non-zero are folded into column bounds inside bslv_lpq_create; what crosses the boundary stays the model as
+    given.  Random LPs with a third of the rows of that kind, solved with the presolve and (BSLV_NO_PRESOLVE) without: same optimal
+    values, and in both cases the returned (x, row activities, row duals, reduced costs) satisfy the optimality conditions of the
+    model AS GIVEN -- r = A x, d = c - A' lambda, every non-zero dual sits on a bound of its variable with the sign of a minimum."""
+    import ctypes
+    import os
+    rng = np.random.default_rng(77)
+    for trial in range(6):
+        M, N = 24, 16
+        A = rng.integers(-3, 4, size=(M, N)).astype(float) * (rng.random((M, N)) < 0.5)
+        single = rng.choice(M, size=8, replace=False)
+        for i in single:
+            A[i] = 0.0
+            A[i, rng.integers(N)] = rng.choice([-2.0, -1.0, 1.0, 3.0])
+        x0 = rng.normal(size=N)
+        r0 = A @ x0
+        lo = np.concatenate([r0 - rng.random(M) * 2, x0 - 1 - rng.random(N)])
+        up = np.concatenate([r0 + rng.random(M) * 2, x0 + 1 + rng.random(N)])
+        lo[rng.choice(M, 6, replace=False)] = -np.inf
+        up[rng.choice(M, 6, replace=False)] = np.inf
+        cost = np.concatenate([[0.0], rng.normal(size=N)])
+        out = {}
+        for mode in ("presolve", "plain"):
+            if mode == "plain":
+                os.environ["BSLV_NO_PRESOLVE"] = "1"
+            try:
+                eng = LpEngine(M, N, A, lo, up, cost, 0, 0, 4)
+            finally:
+                os.environ.pop("BSLV_NO_PRESOLVE", None)
+            eng.lib.bslv_lpq_rows_folded.argtypes = [ctypes.c_void_p]
+            nf = eng.lib.bslv_lpq_rows_folded(eng.h)
+            assert (nf > 0) == (mode == "presolve"), (mode, nf)
+            eng.reset_slot(0)
+            st, it = eng.solve_batch([0], [0], np.zeros((1, 0)), np.zeros((1, 0)))
+            assert st[0] == 4, (trial, mode, st)
+            z = eng.obj([0])[0]
+            prim = eng.primal([0], 0, M + N)[0]
+            dual = eng.dual([0], 0, M + N)[0]
+            eng.close()
+            x, r, lam, d = prim[M:], prim[:M], dual[:M], dual[M:]
+            np.testing.assert_allclose(r, A @ x, atol=1e-9)
+            np.testing.assert_allclose(z, cost[0] + cost[1:] @ x, atol=1e-9)
+            np.testing.assert_allclose(d, cost[1:] - A.T @ lam, atol=1e-8)
+            assert np.all(prim >= lo - 1e-8) and np.all(prim <= up + 1e-8)
+            for k in range(M + N):
+                if abs(dual[k]) > 1e-9:                       # a variable with a non-zero dual sits on the bound of the matching sign
+                    at_lo, at_up = abs(prim[k] - lo[k]) < 1e-7, abs(prim[k] - up[k]) < 1e-7
+                    assert (dual[k] > 0 and at_lo) or (dual[k] < 0 and at_up) or (at_lo and at_up), (trial, mode, k, dual[k], prim[k], lo[k], up[k])
+            out[mode] = z
+        assert abs(out["presolve"] - out["plain"]) < 1e-9 * (1 + abs(out["plain"]))
