@@ -9,8 +9,11 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "S-mid"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 prob = synth.CONFIGS[cfg]()
 model = P2Model(prob)
-print(cfg, "LP", model.M, "x", model.N, flush=True)
 eng = LpEngine.from_model(model, pool_slots=B + 1)
+import ctypes
+eng.lib.bslv_lpq_rows_folded.argtypes = [ctypes.c_void_p]
+folded = eng.lib.bslv_lpq_rows_folded(eng.h)
+print(cfg, "LP", model.M - folded, "x", model.N, "(tableau; model as given %d x %d, %d rows folded into column bounds by the LP layer)" % (model.M, model.N, folded), flush=True)
 print("slot bytes", eng.slot_bytes(), flush=True)
 eng.set_profile(True)
 rng = np.random.default_rng(0)
@@ -33,7 +36,7 @@ for scale in (0.01, 0.1, 1.0):
     dt = time.time() - t
     s = eng.last_stats()
     piv = s["pivots"]
-    bytes_pass = s["passes"] * 16.0 * (model.M + 1) * (model.N + 1)         # one read + one write of the tableau per (LP, pass)
+    bytes_pass = s["passes"] * 16.0 * (model.M - folded + 1) * (model.N + 1)         # one read + one write of the tableau per (LP, pass)
     print("scale %.2f: B=%d ok=%d pivots/LP mean %.1f max %d rounds %d passes %d pivots %d total %.1f ms flush %.1f ms -> %.0f LPs/s, k_flush %.0f GB/s (tableau passes), %.0f GB/s per-pivot equivalent"
           % (scale, B, int((st == 4).sum()), it.mean(), it.max(), s["lockstep_iters"], s["passes"], piv, dt * 1e3, s["update_ms"],
              B / dt, bytes_pass / (s["update_ms"] * 1e-3) / 1e9, bytes_pass / max(s["passes"], 1) * piv / (s["update_ms"] * 1e-3) / 1e9), flush=True)

@@ -10,7 +10,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         acc[name][0] += float(r["Counter_Value"])
         acc[name][1] += 1
     return acc
