@@ -209,7 +209,14 @@ def unmatched_points(a, b, tol):
     return n
 
 
-def assert_benson_results_agree(a, b, c=None, tol=1e-6, allow_sliver=None):
+# End-to-end comparisons (two LP solvers in the loop): 1e-8.  Measured at 1e-9 (BSLV_TEST_TOL=1e-9, round 3): the ex/*.vlp suite
+# passes at 1e-9 (tests/test_cli_gpu.py EX_TOL); on the synthetic problems 8 of 11 884 coordinates differ by up to 5e-9 between the
+# HIP engine and the CPU oracle -- the weights w of a cut are LP duals after a few hundred pivots on tableaux that are never
+# refactorised, on both sides at the solvers' own 1e-9 tolerances.  Index sets stay exact at every tolerance.
+DEFAULT_TOL = 1e-8
+
+
+def assert_benson_results_agree(a, b, c=None, tol=None, allow_sliver=None):
     """Compare two canonicalised Benson results: index sets (adjacency, incidence, dual adjacency) EXACTLY, coordinates within
     `tol`.  Returns "exact".
 
@@ -220,6 +227,8 @@ def assert_benson_results_agree(a, b, c=None, tol=1e-6, allow_sliver=None):
     summed) without a partner within `tol`, vertex counts within max_unmatched, and each polyhedron must contain the other's
     vertices within `tol`; returns "sliver".  Every call is recorded in PARITY_MODES; the session summary (conftest.py) and
     gpurun_out/parity_modes.json list the comparisons that were not exact."""
+    if tol is None:
+        tol = float(os.environ.get("BSLV_TEST_TOL", DEFAULT_TOL))
     exact_error = None
     if a["X"].shape == b["X"].shape and a["Y"].shape == b["Y"].shape:
         try:
