@@ -42,8 +42,8 @@ def main():
     ap.add_argument("--sib-cap", type=int, default=1)
     ap.add_argument("--sib-window", type=int, default=8)
     ap.add_argument("--fronts", type=int, default=8, help="policy 4: number of depth-first fronts")
-    ap.add_argument("--fam-mode", type=int, default=2, help="policy 6: parents newest first (0), pseudo-random (1), far apart (2)")
-    ap.add_argument("--fam-batches", type=int, default=2, help="policy 6: parents among the cuts of the last N outer iterations")
+    ap.add_argument("--fam-mode", type=int, default=3, help="policy 6: parents newest first (0), pseudo-random (1), far apart (2)")
+    ap.add_argument("--fam-batches", type=int, default=1, help="policy 6: parents among the cuts of the last N outer iterations")
     ap.add_argument("--pool", type=int, default=0, help="tableau slots (default 4*batch+64)")
     ap.add_argument("--no-pair", action="store_true", help="skip the S-small whole-run GPU/CPU pair of cpu_baseline")
     ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
@@ -330,7 +330,7 @@ def main():
                        "parallelism": "vertex batch sharded over %d GPU(s), one all-gather of cut records per step (in the library), cut application replicated" % world,
                        "transport": transport,
                        "lp_poly_overlap": pipe is not None,
-                       "tableau_slot_bytes": slot_bytes, "pool_slots": pool_slots, "batch_policy": args.policy or 1, "ramp_steps_untimed": ramp_steps},
+                       "tableau_slot_bytes": slot_bytes, "pool_slots": pool_slots, "batch_policy": args.policy or "6 (library default: whole families, children of the shallowest cuts of the last batch first)", "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
             "live_vertices": live, "poly_rounds": eng.poly_call("rounds_run") - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": {"collect": round(phase_ms[0] / args.steps, 2), "lp": round(phase_ms[1] / args.steps, 2), "cuts": round(phase_ms[2] / args.steps, 2)}, "update_kernel_ms_rank0": round(upd_ms, 2),

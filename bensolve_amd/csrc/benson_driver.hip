@@ -60,9 +60,10 @@ struct bslv_benson {
     // policy 6: the batch is made of whole FAMILIES -- all unprocessed children of a cut -- of parents chosen among the cuts of
     // the last fam_batches outer iterations: fam_mode 0 newest cuts first, 1 pseudo-random, 2 far apart (farthest-point sampling on
     // the cuts' normals), so that the families of one batch act on different neighbourhoods of the polyhedron
-    int fam_mode = 2, fam_batches = 2;
+    int fam_mode = 3, fam_batches = 1;
     std::deque<int> batch_f0;                         // first dual slot of each of the last outer iterations
     std::vector<double> facet_normal;                 // q per dual slot (zeros where unknown)
+    std::vector<double> facet_z;                      // per dual slot: optimal value z of the LP that returned the cut (how deep it cuts; 0 where unknown)
     long collect_seq = 0;
     bool started = false;
     // batch contexts (after collect).  Two of them so that the LPs of batch k can run (on the LP engine's
@@ -76,7 +77,7 @@ struct bslv_benson {
     int mark_at_collect = 0;                          // pipelined mode: batch members get the sltn mark when collected
     int rank = 0, world = 1;
     int unprocessed_left = 0;
-    int policy = 1;                                   // 1: newest vertices first (depth first), 2: spread over the whole queue, 3: newest first, few siblings
+    int policy = 6;                                   // 6 (default since round 3): whole families, the children of the shallowest cuts of the last batch first; 1: newest vertices first (rounds 1-2), 2: spread over the whole queue, 3: newest first, few siblings, 4: fronts, 5: children of the newest cuts
     int sib_cap = 1, sib_window = 8;                  // policy 3: children of one cut per batch; depth of the window in batches
     std::vector<double> slot_src;                     // per slot: vertex its LP was solved for (pool_slots x q)
     std::vector<char> slot_valid;
@@ -202,6 +203,15 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
     rc = bslv_poly_create(&h->poly, q, 1 /* lowerV2upperH */, c);
     if (rc) { bslv_benson_destroy(h); return rc; }
     h->pool_slots = pool_slots;
+    if (const char *e = getenv("BSLV_POLICY")) {         // tuning: "policy[:a[:b]]" -- 3:cap:window, 4:fronts:cap, 6:mode:batches
+        int pol = 0, a = -1, b = -1;
+        if (sscanf(e, "%d:%d:%d", &pol, &a, &b) >= 1 && pol >= 1 && pol <= 6) {
+            h->policy = pol;
+            if (pol == 3 && a > 0) { h->sib_cap = a; if (b > 0) h->sib_window = b; }
+            if (pol == 4 && a > 0) { h->nfronts = a; if (b > 0) h->sib_cap = b; }
+            if (pol == 6 && a >= 0 && a <= 5) { h->fam_mode = a; if (b > 0) h->fam_batches = b; }
+        }
+    }
     for (int s = pool_slots - 1; s >= 1; s--) h->free_slots.push_back(s);
     h->slot_src.assign((size_t)pool_slots * q, 0.0);
     h->slot_valid.assign(pool_slots, 0);
@@ -327,7 +337,17 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
         } else {
             std::vector<int> ord(cand.size());
             for (size_t t = 0; t < ord.size(); t++) ord[t] = (int)t;
-            if (h->fam_mode == 1) {
+            if (h->fam_mode >= 3) {
+                // by the depth z of the parent cut: 3 shallowest first (the finest scale: children next to their parent, few pivots), 4 deepest
+                // first, 5 pseudo-random among the shallower half
+                auto zz = [&](int f) { return f < (int)h->facet_z.size() ? h->facet_z[f] : 0.0; };
+                auto hsh = [&](int f) { unsigned long long z = (unsigned long long)f * 0x9E3779B97F4A7C15ull + (unsigned long long)h->collect_seq * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+                std::sort(ord.begin(), ord.end(), [&](int a, int b) { const double za = zz(cand[a]), zb = zz(cand[b]); if (za != zb) return h->fam_mode == 4 ? za > zb : za < zb; return cand[a] > cand[b]; });
+                if (h->fam_mode == 5) {
+                    const size_t half = std::max<size_t>(1, ord.size() / 2);
+                    std::sort(ord.begin(), ord.begin() + half, [&](int a, int b) { return hsh(cand[a]) < hsh(cand[b]); });
+                }
+            } else if (h->fam_mode == 1) {
                 auto hsh = [&](int f) { unsigned long long z = (unsigned long long)f * 0x9E3779B97F4A7C15ull + (unsigned long long)h->collect_seq * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
                 std::sort(ord.begin(), ord.end(), [&](int a, int b) { return hsh(cand[a]) < hsh(cand[b]); });
             } else std::reverse(ord.begin(), ord.end());
@@ -753,6 +773,8 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     h->batch_f0.push_back(f0);
     while (h->batch_f0.size() > 64) h->batch_f0.pop_front();
     h->facet_normal.resize((size_t)(f0 + ncut) * q, 0.0);
+    h->facet_z.resize((size_t)(f0 + ncut), 0.0);
+    for (int c = 0; c < ncut; c++) h->facet_z[f0 + c] = records[(size_t)cut_src[c] * RL + 3];
     for (int c = 0; c < ncut; c++) {                  // normal of the cut y*: (y*_1 .. y*_{q-1}, 1 - c.y*) (lowerV2upperH, bslv_algs.c:287-305), scaled to length 1
         double *nn = &h->facet_normal[(size_t)(f0 + c) * q];
         const double *ys = &cuts[(size_t)c * q];
@@ -842,7 +864,7 @@ int bslv_benson_set_policy(bslv_benson *h, int policy)
 }
 int bslv_benson_set_families(bslv_benson *h, int mode, int batches)
 {
-    if (!h || mode < 0 || mode > 2 || batches < 1 || batches > 64) return BSLV_E_ARG;
+    if (!h || mode < 0 || mode > 5 || batches < 1 || batches > 64) return BSLV_E_ARG;
     h->fam_mode = mode; h->fam_batches = batches;
     return 0;
 }

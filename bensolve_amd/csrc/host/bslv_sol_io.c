@@ -149,13 +149,15 @@ int bslv_sol_write_preimages(bslv_benson *eng, const char *base, const char *suf
     unsigned char *pu = (unsigned char *)malloc(nv + 1), *pi = (unsigned char *)malloc(nv + 1);
     unsigned char *du = (unsigned char *)malloc(nf + 1), *di = (unsigned char *)malloc(nf + 1);
     double *X = (double *)malloc((size_t)(nv + 1) * d * sizeof(double)), *Y = (double *)malloc((size_t)(nf + 1) * d * sizeof(double));
-    int rc;
-    if ((rc = bslv_poly_get_primal(poly, pu, pi, NULL, X)) || (rc = bslv_poly_get_dual(poly, du, di, Y))) return rc;
-    char path[1024];
     double *row = (double *)malloc((size_t)(m + n + d + 1) * sizeof(double));
+    FILE *f = NULL;
+    int rc = BSLV_E_NOMEM;
+    char path[1024];
+    if (!pu || !pi || !du || !di || !X || !Y || !row) goto out;           /* (one way out: every buffer and the open file are released there) */
+    if ((rc = bslv_poly_get_primal(poly, pu, pi, NULL, X)) || (rc = bslv_poly_get_dual(poly, du, di, Y))) goto out;
+    rc = BSLV_E_ARG;
     snprintf(path, sizeof path, "%s_pre_img_p%s", base, suffix);
-    FILE *f = fopen(path, "w");
-    if (!f) return BSLV_E_ARG;
+    if (!(f = fopen(path, "w"))) goto out;
     for (int i = 0; i < nv; i++) {
         if (!pu[i]) continue;
         if (bslv_benson_preimage_p(eng, i, row)) for (int k = 0; k < n; k++) row[k] = 0.0;
@@ -164,8 +166,7 @@ int bslv_sol_write_preimages(bslv_benson *eng, const char *base, const char *suf
     }
     fclose(f);
     snprintf(path, sizeof path, "%s_pre_img_d%s", base, suffix);
-    f = fopen(path, "w");
-    if (!f) return BSLV_E_ARG;
+    if (!(f = fopen(path, "w"))) goto out;
     for (int k2 = 0; k2 < nf; k2++) {
         if (!du[k2]) continue;
         if (di[k2] || bslv_benson_preimage_d(eng, k2, row)) for (int k = 0; k < m + d; k++) row[k] = 0.0;
@@ -174,8 +175,12 @@ int bslv_sol_write_preimages(bslv_benson *eng, const char *base, const char *suf
         fprintf(f, "\n");
     }
     fclose(f);
+    f = NULL;
+    rc = 0;
+out:
+    if (f) fclose(f);
     free(pu); free(pi); free(du); free(di); free(X); free(Y); free(row);
-    return 0;
+    return rc;
 }
 
 /* option -s with the dual algorithm (poly_output(..., SWAP, ...) with PRE_IMG_ON, bslv_algs.c:1566-1573): the polyhedron holds the
@@ -186,13 +191,15 @@ int bslv_sol_write_preimages_dual(bslv_poly *poly, const char *base, const char 
     const int d = bslv_poly_dim(poly), nv = bslv_poly_nprimal(poly), nf = bslv_poly_ndual(poly);
     unsigned char *pu = (unsigned char *)malloc(nv + 1), *pi = (unsigned char *)malloc(nv + 1);
     unsigned char *du = (unsigned char *)malloc(nf + 1), *di = (unsigned char *)malloc(nf + 1);
-    int rc;
-    if ((rc = bslv_poly_get_primal(poly, pu, pi, NULL, NULL)) || (rc = bslv_poly_get_dual(poly, du, di, NULL))) return rc;
-    char path[1024];
     double *row = (double *)malloc((size_t)(m + n + d + 1) * sizeof(double));
+    FILE *f = NULL;
+    int rc = BSLV_E_NOMEM;
+    char path[1024];
+    if (!pu || !pi || !du || !di || !row) goto out;
+    if ((rc = bslv_poly_get_primal(poly, pu, pi, NULL, NULL)) || (rc = bslv_poly_get_dual(poly, du, di, NULL))) goto out;
+    rc = BSLV_E_ARG;
     snprintf(path, sizeof path, "%s_pre_img_p%s", base, suffix);
-    FILE *f = fopen(path, "w");
-    if (!f) return BSLV_E_ARG;
+    if (!(f = fopen(path, "w"))) goto out;
     for (int k2 = 0; k2 < nf; k2++) {
         if (!du[k2]) continue;
         if (bslv_dual_preimage_x(poly, k2, row)) for (int k = 0; k < n; k++) row[k] = 0.0;
@@ -201,8 +208,7 @@ int bslv_sol_write_preimages_dual(bslv_poly *poly, const char *base, const char 
     }
     fclose(f);
     snprintf(path, sizeof path, "%s_pre_img_d%s", base, suffix);
-    f = fopen(path, "w");
-    if (!f) return BSLV_E_ARG;
+    if (!(f = fopen(path, "w"))) goto out;
     for (int i = 0; i < nv; i++) {
         if (!pu[i]) continue;
         if (pi[i] || bslv_dual_preimage_uw(poly, i, row)) for (int k = 0; k < m + d; k++) row[k] = 0.0;
@@ -211,6 +217,10 @@ int bslv_sol_write_preimages_dual(bslv_poly *poly, const char *base, const char 
         fprintf(f, "\n");
     }
     fclose(f);
+    f = NULL;
+    rc = 0;
+out:
+    if (f) fclose(f);
     free(pu); free(pi); free(du); free(di); free(row);
-    return 0;
+    return rc;
 }

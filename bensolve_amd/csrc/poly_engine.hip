@@ -2626,8 +2626,8 @@ struct bslv_poly {
     int r2_fuse = 0;                  // (default 0: measured fastest) 1: the classification of a round's new vertices rides in the launch of its prunes (extra workgroups); 2: and the last prune workgroup to finish writes the adjacent pairs (a ticket; measured slower); 0: three launches (BSLV_R2_FUSE / debug_set key 13)
     bool r2_spec = true;              // rounds are queued one ahead of the host (BSLV_R2_SPEC=0 / debug_set key 12: the host reads every round's mailbox before it queues the next)
     long r2_spec_void = 0;            // rounds that were queued ahead and found the device halted (bslv_poly_rounds2_stats)
-    bool r2_mis = false;              // BSLV_R2_MIS=1 / debug_set key 11: rounds take a MAXIMAL independent set from a conflict matrix of the chunk (round 3; measured no faster on S-mid)
-    int chunk_cuts = 512;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
+    bool r2_mis = true;               // rounds take a MAXIMAL independent set from a conflict matrix of the chunk (round 3); BSLV_R2_MIS=0 / debug_set key 11: the local minima of one random order (round 2)
+    int chunk_cuts = 1024;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
     int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
     int r2_min_cuts = 0;              // rounds go on while they hold at least this many cuts on average (debug_set key 8; 0: until the rounds hold one cut each; -1: always)
     long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0, r2_late_left = 0, r2_torn_reads = 0;

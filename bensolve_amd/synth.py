@@ -97,6 +97,11 @@ CONFIGS = {
     # record the change"): q = 4 ends after 1.7e5 LPs / 3.3e4 facets; q = 5 at n = 200 after 4.2e6 LPs / 7.2e5 facets
     "S-degenerate-q4": lambda: degenerate_vlp(4000, 2000, 4, 3),
     "S-degenerate-q5-n200": lambda: degenerate_vlp(400, 200, 5, 3),
+    # covering problems of the S-mid recipe that TERMINATE on one GPU in seconds to minutes: the whole-run yardstick of a batch
+    # selection rule (S-mid itself never terminates: its steady state is an ever-growing frontier)
+    "C-q4-300": lambda: covering_vlp(300, 150, 4, 11),
+    "C-q4-400": lambda: covering_vlp(400, 200, 4, 9),
+    "C-q5-120": lambda: covering_vlp(120, 60, 5, 7),
 }
 
 
