@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--fam-mode", type=int, default=3, help="policy 6: parents newest first (0), pseudo-random (1), far apart (2)")
     ap.add_argument("--fam-batches", type=int, default=1, help="policy 6: parents among the cuts of the last N outer iterations")
     ap.add_argument("--pool", type=int, default=0, help="tableau slots (default 4*batch+64)")
+    ap.add_argument("--no-long-window", action="store_true", help="skip the continuation of the run to 5x the steps (reported as long_window, not part of value)")
     ap.add_argument("--no-pair", action="store_true", help="skip the S-small whole-run GPU/CPU pair of cpu_baseline")
     ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
     args = ap.parse_args()
@@ -195,10 +196,33 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     eng.lp_call("set_profile", False)
-    c1 = eng.poly_call("counts")
+    # the counters of the timed region, before anything else runs on this engine
+    snap = {"counts": eng.poly_call("counts"), "rounds_run": eng.poly_call("rounds_run"), "path_stats": eng.poly_call("path_stats"),
+            "health": eng.poly_call("rounds2_health"), "starts": eng.start_stats(), "totals": eng.totals()}
+    snap["live"] = int(eng.poly_dump()["pu"].sum()) if snap["counts"]["nprimal"] < 5_000_000 else -1
+    phase_timed = list(phase_ms)         # (a copy: one_step() keeps adding to phase_ms if the run goes on below)
+    # Everything the headline needs is measured.  Two more figures for the reader, outside the timed region (rank 0, one GPU):
+    #  * long_window: the SAME run continued to 5x the steps -- S-mid never terminates, the polyhedron keeps growing, and the rate
+    #    of the first steps after the ramp is not the rate of a long run;
+    #  * below, after the CPU baseline: the batch selection rule of rounds 1-2 (newest vertices first) on a fresh engine.
+    long_window = None
+    if world == 1 and pipe is None and args.workload == "S-mid" and not args.no_long_window:
+        extra = 4 * args.steps
+        l2 = c2 = f2 = 0
+        tl = time.perf_counter()
+        for _ in range(extra):
+            s = one_step()
+            l2 += s["lps"]; c2 += s["cuts"]; f2 += s.get("confirmed", 0)
+        sync()
+        dtl = time.perf_counter() - tl
+        long_window = {"steps": args.steps + extra, "lps_per_sec": round((lps + l2) / (dt + dtl), 1), "useful_lps_per_sec": round((cuts + confirmed + c2 + f2) / (dt + dtl), 1),
+                       "continuation_only": {"lps_per_sec": round(l2 / dtl, 1), "useful_lps_per_sec": round((c2 + f2) / dtl, 1)},
+                       "note": "the timed region plus 4x as many steps of the same run (not part of `value`)"}
+
+    c1 = snap["counts"]
     new_vertices = c1["new_vertices"] - nv0
     pair_tests = c1["pair_tests"] - pt0
-    live = int(eng.poly_dump()["pu"].sum()) if c1["nprimal"] < 5_000_000 else -1
+    live = snap["live"]
 
     # spread of the headline: the rate over consecutive windows of the timed region (>= 3 windows; rank 0's clock)
     nwin = min(5, args.steps) if args.steps >= 3 else 1
@@ -209,14 +233,14 @@ def main():
             ta = t0 if a == 0 else step_t[a - 1]
             win_rates.append(sum(step_lps[a:b]) / max(step_t[b - 1] - ta, 1e-9))
     win_rates.sort()
-    starts = eng.start_stats()
+    starts = snap["starts"]
     # max over ranks of the elapsed time; sums of the per-rank pivot counts
     if world > 1:
         cdev = torch.device("cpu") if rehearsal else device       # (gloo: host tensors)
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        agg = torch.tensor([pivots, upd_ms, eng.totals()["lps"], starts["root"], starts["nearest"]], dtype=torch.float64, device=cdev)
+        agg = torch.tensor([pivots, upd_ms, snap["totals"]["lps"], starts["root"], starts["nearest"]], dtype=torch.float64, device=cdev)
         allp = [torch.zeros_like(agg) for _ in range(world)]
         dist.all_gather(allp, agg)
         pivots_all = sum(float(a[0]) for a in allp)
@@ -254,17 +278,17 @@ def main():
     # second figure of merit: the cut phase (bslv_poly's half of the path).  Not HBM-bound (integer / LDS /
     # latency): reported as time per cut, cuts per pass over the polyhedron, and pair tests per second next to the
     # reference's own bslv_poly.c on one core (6.9e6/s at q=5, N=1000).
-    cut_ms = phase_ms[2]
-    passes_poly = eng.poly_call("rounds_run") - rounds0
-    ps = eng.poly_call("path_stats")
-    roofline_cuts = {"bound": "latency/integer (not hbm)", "kernels": "k_flags2+k_emit2+k2_fused per single cut; k_classify_batch_t+k_edge_emit_m+k_pair_flags_m per multi-cut pass",
+    cut_ms = phase_timed[2]
+    passes_poly = snap["rounds_run"] - rounds0
+    ps = snap["path_stats"]
+    roofline_cuts = {"bound": "latency/integer (not hbm)", "kernels": "per round of independent cuts: k_r2_minit (conflict matrix, LDS) + k_r2_select3 (maximal independent set) + k_r2_assign3 + k_flags2 + k_r2_emit + k_r2_classify3 + k2_fused_t<true> (one prune per selected cut) + k_r2_k2emit; k_flags2+k_emit2+k2_fused per single cut",
                      "cuts_applied": cuts, "cuts_per_step": round(cuts / max(args.steps, 1), 1),
                      "us_per_cut": round(cut_ms * 1e3 / max(cuts, 1), 2) if world == 1 and pipe is None else None,
                      "passes_over_polyhedron": passes_poly, "cuts_per_pass": round(cuts / max(passes_poly, 1), 2),
                      "single_cut_pipeline_cuts": ps["single_cuts"] - ps0["single_cuts"], "hot_chunks": ps["hot_chunks"] - ps0["hot_chunks"],
                      "pair_tests_per_sec": round(pair_tests / dt, 1), "reference_pair_tests_per_sec_1core": 6.9e6,
-                     "mailbox": eng.poly_call("rounds2_health"),
-                     "note": "a single cut runs on ~10^2 workgroups for ~50 us (dependent chain of 3 launches); a multi-cut pass applies all independent cuts of a batch in one sweep"}
+                     "mailbox": snap["health"],
+                     "note": "a round applies a maximal set of mutually independent cuts of the chunk (<= 1024 cuts) in the passes of one cut: ~250 us of dependent small launches, latency-bound (profiles/r03_cut_phase_counters.json: 64-92 % of wave cycles waiting)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload.startswith("S-degenerate") and not args.cpu_lps:
@@ -300,6 +324,27 @@ def main():
                                 "vertices_per_sec": round(rb[4], 1),
                                 "note": "same oracle, vertices taken newest first as the batched driver does: the best sequential order for warm starts"},
                "every_lp_useful": True}
+        if args.workload == "S-mid" and not args.policy and not args.no_long_window:
+            # the batch selection rule of rounds 1-2 on a fresh engine, same ramp / warm-up / steps: what BENCH_r01 / r02 measured
+            e3 = BensonEngine(prob, eps=1e-7, pool_slots=pool_slots)
+            e3.set_policy(1)
+            e3.poly_call("debug_set", 11, 0); e3.poly_call("debug_set", 7, 512)      # (rounds by local minima, chunks of 512: round 2's cut phase)
+            e3.start()
+            for _ in range(200):
+                e3.step(B)
+                if e3.poly_call("unprocessed", 0)[3] >= B:
+                    break
+            for _ in range(args.warmup):
+                e3.step(B)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            l3 = c3 = 0
+            for _ in range(args.steps):
+                s3 = e3.step(B)
+                l3 += s3["lps"]; c3 += s3["cuts"] + s3["confirmed"]
+            torch.cuda.synchronize(); t3 = time.perf_counter() - t3
+            e3.close()
+            cpu["policy_newest_first_rounds_of_local_minima"] = {"lps_per_sec": round(l3 / t3, 1), "useful_lps_per_sec": round(c3 / t3, 1), "lps_redundant_frac": round(1 - c3 / max(l3, 1), 4),
+                                                                  "note": "rounds 1-2's selection (newest vertices first) and cut phase (local minima of one order, chunks of 512) on a fresh engine over the same window; not part of `value`"}
         if not args.no_pair and args.workload != "S-small":
             # like-for-like pair: S-small to termination on both sides (same problem, same eps, whole phase 2)
             sp = synth.CONFIGS["S-small"]()
@@ -333,9 +378,10 @@ def main():
                        "tableau_slot_bytes": slot_bytes, "pool_slots": pool_slots, "batch_policy": args.policy or "6 (library default: whole families, children of the shallowest cuts of the last batch first)", "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
-            "live_vertices": live, "poly_rounds": eng.poly_call("rounds_run") - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": {"collect": round(phase_ms[0] / args.steps, 2), "lp": round(phase_ms[1] / args.steps, 2), "cuts": round(phase_ms[2] / args.steps, 2)}, "update_kernel_ms_rank0": round(upd_ms, 2),
+            "live_vertices": live, "poly_rounds": snap["rounds_run"] - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": {"collect": round(phase_timed[0] / args.steps, 2), "lp": round(phase_timed[1] / args.steps, 2), "cuts": round(phase_timed[2] / args.steps, 2)}, "update_kernel_ms_rank0": round(upd_ms, 2),
             "warm_starts": {"per_rank": per_rank, "note": "LPs whose parent's tableau was not resident on the rank that solved them start from the nearest resident tableau (else from the root tableau): the hit rate of the dealing rule"},
             "useful_vs_cpu_baseline": round(((cuts + confirmed) / dt) / cpu["value"], 1) if cpu and cpu.get("value") else None,
+            "long_window": long_window,
             "roofline": roofline, "roofline_cuts": roofline_cuts, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
