@@ -354,3 +354,68 @@ def test_pool_is_cut_to_the_free_device_memory():
         s = eng.step(4096)
     assert s["lps"] > 0 and s["failed"] == 0
     eng.close()
+
+
+@pytest.mark.parametrize("policy", ["1", "5", "6:0:1", "6:1:2", "6:3:1", "6:5:2", "4:4:8"])
+def test_every_batch_selection_rule_builds_the_same_upper_image(policy, monkeypatch):
+    """The batch selection rules (round 3: whole families of siblings, ordered by the depth of the parent cut -- the default --, at
+    random, by the age of the cut; fronts; the rounds-1-2 rule 'newest vertices first') only decide WHICH unprocessed vertices an outer
+    iteration solves for.  Run to termination at eps = POLY_EPS they must all arrive at the upper image of the sequential CPU oracle:
+    vertices, facets, incidence, adjacency as exact sets."""
+    prob = synth.covering_vlp(40, 20, 3, 21)
+    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=1e-9)
+    assert rc == 0
+    fp.dual_adjacency()
+    exp = ph.canonical(fp.dump(), decimals=6)
+    fp.close()
+    monkeypatch.setenv("BSLV_POLICY", policy)
+    eng = BensonEngine(prob, eps=1e-9, pool_slots=4 * 64 + 64)
+    assert eng.start() == 0
+    steps = eng.run(64)
+    left = eng.poly_call("unprocessed", 0)[3]
+    eng.poly_call("dual_adjacency")
+    got = ph.canonical(eng.poly_dump(), decimals=6)
+    eng.close()
+    assert left == 0 and steps > 3
+    assert ph.assert_benson_results_agree(got, exp) == "exact"
+
+
+def test_families_of_unprocessed_vertices():
+    """bslv_poly_children_hist / bslv_poly_children_of (the selection by families): the histogram over parent facets adds up to the
+    unprocessed elements, and the children of all facets with a count are exactly those elements, each with the newest facet through
+    it as its parent."""
+    import ctypes
+    prob = synth.covering_vlp(60, 30, 4, 5)
+    eng = BensonEngine(prob, eps=1e-7, pool_slots=512)
+    assert eng.start() == 0
+    for _ in range(6):
+        eng.step(64)
+    lib, ph_ = eng.lib, eng._poly_h
+    lib.bslv_poly_children_hist.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+    lib.bslv_poly_children_of.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+    nf = lib.bslv_poly_ndual(ph_)
+    counts = np.zeros(nf, np.int32)
+    total, older = ctypes.c_int(), ctypes.c_int()
+    assert lib.bslv_poly_children_hist(ph_, 0, nf, counts.ctypes.data, ctypes.byref(total), ctypes.byref(older)) == 0
+    idx_all, val_all, ideal_all, cnt_all = eng.poly_call("unprocessed")
+    assert total.value == cnt_all == counts.sum() and older.value == 0 and cnt_all > 100
+    fac = np.ascontiguousarray(np.nonzero(counts)[0], np.int32)
+    q = prob["q"]
+    idx = np.zeros(cnt_all, np.int32); val = np.zeros((cnt_all, q)); ideal = np.zeros(cnt_all, np.int32); par = np.zeros(cnt_all, np.int32)
+    n = ctypes.c_int()
+    assert lib.bslv_poly_children_of(ph_, len(fac), fac.ctypes.data, cnt_all, idx.ctypes.data, val.ctypes.data, ideal.ctypes.data, par.ctypes.data, ctypes.byref(n)) == 0
+    assert n.value == cnt_all
+    assert np.array_equal(idx, idx_all) and np.array_equal(val, val_all) and np.array_equal(ideal, ideal_all)
+    assert np.array_equal(np.bincount(par, minlength=nf), counts)
+    # one family alone: the facet with the most children
+    f = int(np.argmax(counts))
+    one = np.array([f], np.int32)
+    assert lib.bslv_poly_children_of(ph_, 1, one.ctypes.data, cnt_all, idx.ctypes.data, val.ctypes.data, ideal.ctypes.data, par.ctypes.data, ctypes.byref(n)) == 0
+    assert n.value == counts[f] and np.all(par[:n.value] == f)
+    # every child lies on its parent's hyperplane
+    d = eng.poly_dump()
+    y = d["Y"][f]
+    w = np.concatenate([y[:-1], [1 - y[:-1].sum()]])
+    pts = ideal[:n.value] == 0
+    assert np.abs(val[:n.value][pts] @ w - y[-1]).max() < 1e-7
+    eng.close()
