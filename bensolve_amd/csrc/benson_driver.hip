@@ -340,7 +340,7 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
             if (h->fam_mode >= 3) {
                 // by the depth z of the parent cut: 3 shallowest first (the finest scale: children next to their parent, few pivots), 4 deepest
                 // first, 5 pseudo-random among the shallower half
-                auto zz = [&](int f) { return f < (int)h->facet_z.size() ? h->facet_z[f] : 0.0; };
+                auto zz = [&](int f) { return f < (int)h->facet_z.size() ? h->facet_z[f] : (double)INFINITY; };
                 auto hsh = [&](int f) { unsigned long long z = (unsigned long long)f * 0x9E3779B97F4A7C15ull + (unsigned long long)h->collect_seq * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
                 std::sort(ord.begin(), ord.end(), [&](int a, int b) { const double za = zz(cand[a]), zb = zz(cand[b]); if (za != zb) return h->fam_mode == 4 ? za > zb : za < zb; return cand[a] > cand[b]; });
                 if (h->fam_mode == 5) {
@@ -773,7 +773,7 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     h->batch_f0.push_back(f0);
     while (h->batch_f0.size() > 64) h->batch_f0.pop_front();
     h->facet_normal.resize((size_t)(f0 + ncut) * q, 0.0);
-    h->facet_z.resize((size_t)(f0 + ncut), 0.0);
+    h->facet_z.resize((size_t)(f0 + ncut), INFINITY);      // (facets whose depth is not known -- those of the start -- count as the deepest)
     for (int c = 0; c < ncut; c++) h->facet_z[f0 + c] = records[(size_t)cut_src[c] * RL + 3];
     for (int c = 0; c < ncut; c++) {                  // normal of the cut y*: (y*_1 .. y*_{q-1}, 1 - c.y*) (lowerV2upperH, bslv_algs.c:287-305), scaled to length 1
         double *nn = &h->facet_normal[(size_t)(f0 + c) * q];

@@ -22,7 +22,7 @@ for path in open("gpurun_out/${tag}_cut_counters.files").read().split():
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         a = acc[name][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
-want = ("k_r2_prep", "k_r2_select", "k_r2_assign", "k_flags2", "k_r2_emit", "k_r2_classify3", "k2_fused_t<true>", "k_r2_k2emit", "k_flush", "k_select")
+want = ("k_r2_minit", "k_r2_select3", "k_r2_assign3", "k_r2_prep", "k_r2_select", "k_r2_assign", "k_flags2", "k_r2_emit", "k_r2_classify3", "k2_fused_t<true>", "k_r2_k2emit", "k_flush", "k_select")
 out = {}
 for name, cs in acc.items():
     if not any(w in name for w in want):

@@ -6,7 +6,7 @@ tag=${1:-rXX}
 export TMPDIR=/tmp
 python3 bench.py > gpurun_out/${tag}_bench_smid.json 2> gpurun_out/${tag}_bench_smid.err || exit 1
 python3 bench.py --workload S-small --no-pair > gpurun_out/${tag}_bench_ssmall.json 2>> gpurun_out/${tag}_bench_smid.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -o ${tag} -- python3 bench.py --no-cpu-baseline > gpurun_out/${tag}_bench_smid_profiled.json 2> gpurun_out/${tag}_prof.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -o ${tag} -- python3 bench.py --no-cpu-baseline --no-long-window > gpurun_out/${tag}_bench_smid_profiled.json 2> gpurun_out/${tag}_prof.err || exit 1
 ks=$(find gpurun_out/prof_${tag} -name "*kernel_stats.csv" | head -1)
 kt=$(find gpurun_out/prof_${tag} -name "*kernel_trace.csv" | head -1)
 cp "$ks" gpurun_out/${tag}_bench_smid_kernel_stats.csv
