@@ -60,7 +60,8 @@ struct bslv_benson {
     // policy 6: the batch is made of whole FAMILIES -- all unprocessed children of a cut -- of parents chosen among the cuts of
     // the last fam_batches outer iterations: fam_mode 0 newest cuts first, 1 pseudo-random, 2 far apart (farthest-point sampling on
     // the cuts' normals), so that the families of one batch act on different neighbourhoods of the polyhedron
-    int fam_mode = 3, fam_batches = 1;
+    int fam_mode = 3, fam_batches = 1, fam_cap = 0;
+    double facet_z0 = getenv("BSLV_FACET_Z0") ? atof(getenv("BSLV_FACET_Z0")) : (double)INFINITY;
     std::deque<int> batch_f0;                         // first dual slot of each of the last outer iterations
     std::vector<double> facet_normal;                 // q per dual slot (zeros where unknown)
     std::vector<double> facet_z;                      // per dual slot: optimal value z of the LP that returned the cut (how deep it cuts; 0 where unknown)
@@ -204,12 +205,12 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
     if (rc) { bslv_benson_destroy(h); return rc; }
     h->pool_slots = pool_slots;
     if (const char *e = getenv("BSLV_POLICY")) {         // tuning: "policy[:a[:b]]" -- 3:cap:window, 4:fronts:cap, 6:mode:batches
-        int pol = 0, a = -1, b = -1;
-        if (sscanf(e, "%d:%d:%d", &pol, &a, &b) >= 1 && pol >= 1 && pol <= 6) {
+        int pol = 0, a = -1, b = -1, c4 = -1;
+        if (sscanf(e, "%d:%d:%d:%d", &pol, &a, &b, &c4) >= 1 && pol >= 1 && pol <= 6) {
             h->policy = pol;
             if (pol == 3 && a > 0) { h->sib_cap = a; if (b > 0) h->sib_window = b; }
             if (pol == 4 && a > 0) { h->nfronts = a; if (b > 0) h->sib_cap = b; }
-            if (pol == 6 && a >= 0 && a <= 5) { h->fam_mode = a; if (b > 0) h->fam_batches = b; }
+            if (pol == 6 && a >= 0 && a <= 5) { h->fam_mode = a; if (b > 0) h->fam_batches = b; if (c4 >= 0) h->fam_cap = c4; }
         }
     }
     for (int s = pool_slots - 1; s >= 1; s--) h->free_slots.push_back(s);
@@ -307,13 +308,13 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
             counts.assign((size_t)std::max(0, nf - f_lo), 0);
             if ((rc = bslv_poly_children_hist(h->poly, f_lo, (int)counts.size(), counts.data(), &total, nullptr))) return rc;
             long in_window = 0;
-            for (int c : counts) in_window += c;
+            for (int c : counts) in_window += h->fam_cap > 0 ? std::min(c, h->fam_cap) : c;
             if (in_window >= max_batch || f_lo == 0) break;
             f_lo = std::max(0, f_lo - std::max(64, 2 * (nf - f_lo)));
         }
         std::vector<int> cand;
         for (int k = 0; k < (int)counts.size(); k++) if (counts[k] > 0) cand.push_back(f_lo + k);
-        long have = 0;
+        long have = 0, full = 0;
         if (h->fam_mode == 2 && (int)h->facet_normal.size() >= nf * q) {
             // far apart: the first parent is the newest cut, every further one the candidate farthest (in the angle of the normals) from
             // all parents taken so far
@@ -321,7 +322,7 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
             std::vector<char> used(cand.size(), 0);
             int cur = cand.empty() ? -1 : (int)cand.size() - 1;
             while (cur >= 0 && have < max_batch) {
-                used[cur] = 1; chosen.push_back(cand[cur]); have += counts[cand[cur] - f_lo];
+                used[cur] = 1; chosen.push_back(cand[cur]); have += counts[cand[cur] - f_lo]; full += counts[cand[cur] - f_lo];
                 const double *nc = &h->facet_normal[(size_t)cand[cur] * q];
                 int nxt = -1; double far = -1;
                 for (size_t t = 0; t < cand.size(); t++) {
@@ -340,7 +341,7 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
             if (h->fam_mode >= 3) {
                 // by the depth z of the parent cut: 3 shallowest first (the finest scale: children next to their parent, few pivots), 4 deepest
                 // first, 5 pseudo-random among the shallower half
-                auto zz = [&](int f) { return f < (int)h->facet_z.size() ? h->facet_z[f] : (double)INFINITY; };
+                auto zz = [&](int f) { return f < (int)h->facet_z.size() ? h->facet_z[f] : h->facet_z0; };
                 auto hsh = [&](int f) { unsigned long long z = (unsigned long long)f * 0x9E3779B97F4A7C15ull + (unsigned long long)h->collect_seq * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
                 std::sort(ord.begin(), ord.end(), [&](int a, int b) { const double za = zz(cand[a]), zb = zz(cand[b]); if (za != zb) return h->fam_mode == 4 ? za > zb : za < zb; return cand[a] > cand[b]; });
                 if (h->fam_mode == 5) {
@@ -351,21 +352,41 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
                 auto hsh = [&](int f) { unsigned long long z = (unsigned long long)f * 0x9E3779B97F4A7C15ull + (unsigned long long)h->collect_seq * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
                 std::sort(ord.begin(), ord.end(), [&](int a, int b) { return hsh(cand[a]) < hsh(cand[b]); });
             } else std::reverse(ord.begin(), ord.end());
-            for (int t : ord) { if (have >= max_batch) break; chosen.push_back(cand[t]); have += counts[cand[t] - f_lo]; }
+            const int cap = h->fam_cap > 0 ? h->fam_cap : INT_MAX;
+            for (int t : ord) { if (have >= max_batch) break; chosen.push_back(cand[t]); have += std::min(cap, counts[cand[t] - f_lo]); full += counts[cand[t] - f_lo]; }
         }
-        std::vector<int> idx(max_batch), ideal(max_batch), parent(max_batch);
-        std::vector<double> val((size_t)max_batch * q);
+        // (with a cap on the children of one cut the device hands over the whole families and the host thins them out)
+        const int fetch = h->fam_cap > 0 ? (int)std::min<long long>(std::max<long long>(full, 1), 16LL * max_batch) : max_batch;
+        std::vector<int> idx(fetch), ideal(fetch), parent(fetch);
+        std::vector<double> val((size_t)fetch * q);
         int n = 0;
-        if (!chosen.empty() && (rc = bslv_poly_children_of(h->poly, (int)chosen.size(), chosen.data(), max_batch, idx.data(), val.data(), ideal.data(), parent.data(), &n))) return rc;
+        if (!chosen.empty() && (rc = bslv_poly_children_of(h->poly, (int)chosen.size(), chosen.data(), fetch, idx.data(), val.data(), ideal.data(), parent.data(), &n))) return rc;
+        std::vector<char> keep;
+        if (h->fam_cap > 0) {
+            // at most fam_cap children of one cut, evenly spaced in the order of their slots (neighbours on the parent's facet have
+            // neighbouring slots); the others stay unprocessed: by the time their turn comes the cuts of their siblings have removed many
+            keep.assign(n, 0);
+            std::unordered_map<int, int> seen;
+            int kept = 0;
+            for (int k = 0; k < n; k++) {
+                if (ideal[k]) { keep[k] = 1; continue; }
+                const int f = parent[k], cnt_f = (f >= f_lo && f - f_lo < (int)counts.size()) ? counts[f - f_lo] : 1, j = seen[f]++;
+                const bool take = cnt_f <= h->fam_cap || (long long)(j + 1) * h->fam_cap / cnt_f != (long long)j * h->fam_cap / cnt_f;
+                if (take && kept < max_batch) { keep[k] = 1; kept++; }
+            }
+        }
+        int nkept = 0;
         std::vector<int> dirs;
         for (int k = 0; k < n; k++) {
+            if (!keep.empty() && !keep[k]) continue;
+            nkept++;
             if (ideal[k]) { dirs.push_back(idx[k]); continue; }
             B.b_idx.push_back(idx[k]);
             B.b_parent.push_back(parent[k]);
             B.b_val.insert(B.b_val.end(), &val[(size_t)k * q], &val[(size_t)(k + 1) * q]);
         }
         if (!dirs.empty() && (rc = bslv_poly_mark(h->poly, (int)dirs.size(), dirs.data()))) return rc;
-        h->unprocessed_left = total - n;
+        h->unprocessed_left = total - nkept;
         // (a window that held only directions: the next call sees them marked)
         return deal_batch(h, B, rank, world, n_local, n_total);
     }
@@ -773,7 +794,7 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     h->batch_f0.push_back(f0);
     while (h->batch_f0.size() > 64) h->batch_f0.pop_front();
     h->facet_normal.resize((size_t)(f0 + ncut) * q, 0.0);
-    h->facet_z.resize((size_t)(f0 + ncut), INFINITY);      // (facets whose depth is not known -- those of the start -- count as the deepest)
+    h->facet_z.resize((size_t)(f0 + ncut), h->facet_z0);      // (facets whose depth is not known -- those of the start -- count as the deepest)
     for (int c = 0; c < ncut; c++) h->facet_z[f0 + c] = records[(size_t)cut_src[c] * RL + 3];
     for (int c = 0; c < ncut; c++) {                  // normal of the cut y*: (y*_1 .. y*_{q-1}, 1 - c.y*) (lowerV2upperH, bslv_algs.c:287-305), scaled to length 1
         double *nn = &h->facet_normal[(size_t)(f0 + c) * q];

@@ -2013,7 +2013,12 @@ __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const uns
 struct RState;
 struct K2V2 {
     const RState *st; const int *cutof; int *mem_g; unsigned *adj_g; int *cnt_g; int *nm_g; int adjw_cap; long long *pair_tests;
+    // prunes whose member lists hold more entries than the LDS hash table takes (extreme directions among the members: lists of
+    // thousands of facets) count in global memory, as the single-cut pipeline does -- each in a slice of its own, handed out by a
+    // ticket per round (fc_ticket[round & 1]; workgroup 0 clears the other one for the next round)
+    int *fc2, *fl2, *fc_ticket; int fc_slices, fc_stride;
 };
+__device__ __forceinline__ int k2v2_round(const RState *st);
 __device__ __forceinline__ void k2v2_sizes(const RState *st, int &S, int &go, int &nzero, int &nv0, int &ncross);
 __device__ void k2v2_check_members(const K2V2 &V, int vs, const int *s_mem, int nm, const int *members, int nzero);
 // (a device function: the kernel of the single-cut pipeline, k2_fused_t<false>, and the prune launch of a round, k_r2_k2, call it)
@@ -2026,6 +2031,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
     if (V2) {
         int S, go;
         k2v2_sizes(V.st, S, go, nzero, nv0, ncross);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && V.fc_ticket) V.fc_ticket[(k2v2_round(V.st) + 1) & 1] = 0;
         if (!go || (int)blockIdx.x >= S) return;
         cd = nullptr; dbg = nullptr; ne_dev = nullptr;
     }
@@ -2083,7 +2089,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
             __syncthreads();
         }
         nm = s_base;
-        if (nm > K2_MAXNM) { v2_result(-1, nm); return; }          // too large for one workgroup: multi-kernel prune
+        if (nm > K2_MAXNM) { v2_result(-1, nm); return; }          // too large for one workgroup: multi-kernel prune (the negative count says why: -1 members, -2 pair bitmap, -3 hash table, -4 bit matrix)
 #ifdef BSLV_R2_CHECK_MEMBERS
         k2v2_check_members(V, vs, s_mem, nm, members, nzero);          // debugging aid, O(nm^2): a member list never holds an element twice
 #endif
@@ -2096,7 +2102,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
     unsigned long long *bits = k2_dyn + (nadjw + 1) / 2;       // (behind the hash table when that is used, see P1)
     const long long bits_cap = (long long)lds_words - (nadjw + 1) / 2;
     if (bits_cap < 0) {                 // not even the pair bitmap fits (uniform): multi-kernel prune
-        if (V2) { v2_result(-1, nm); return; }
+        if (V2) { v2_result(-2, nm); return; }
         if (threadIdx.x == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; mail->seq = seq; }
         return;
     }
@@ -2131,7 +2137,14 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
     }
     __syncthreads();
     const bool use_hash = 2 * s_total <= K2_HASH && (long long)K2_HASH <= bits_cap;        // load factor <= 1/2 (uniform)
-    if (V2 && !use_hash) { v2_result(-1, nm); return; }
+    if (V2 && !use_hash) {
+        __shared__ int s_slice;
+        if (tid == 0) s_slice = V.fc_slices > 0 ? atomicAdd(&V.fc_ticket[k2v2_round(V.st) & 1], 1) : V.fc_slices;
+        __syncthreads();
+        if (s_slice >= V.fc_slices) { v2_result(-3, nm); return; }
+        fcount = V.fc2 + (size_t)s_slice * V.fc_stride;
+        flocal = V.fl2 + (size_t)s_slice * V.fc_stride;
+    }
     int *hkey = (int *)bits, *hval = hkey + K2_HASH;                 // the table sits in front of the bit matrix
     if (use_hash) bits += K2_HASH;                                   // (K2_HASH ints of keys + K2_HASH of values = K2_HASH 64-bit words)
     const long long bcap = use_hash ? bits_cap - K2_HASH : bits_cap;
@@ -2161,7 +2174,11 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
     K2_PHASE(2);
     const int W = (s_nloc + 63) >> 6, NW = (nm + 63) >> 6;
     unsigned long long *rows = bits + W * nm;        // rows[f * NW + k]: members on local facet f
-    if (V2 && (long long)W * nm + (long long)W * 64 * NW > bcap) { v2_result(-1, nm); return; }
+    if (V2 && (long long)W * nm + (long long)W * 64 * NW > bcap) {
+        if (!use_hash) k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
+        v2_result(-4, nm);
+        return;
+    }
     if ((long long)W * nm + (long long)W * 64 * NW > bcap) {             // uniform: every thread sees the same s_nloc
         if (!use_hash) k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
         if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; mail->seq = seq; }
@@ -2607,6 +2624,7 @@ __device__ void k2v2_check_members(const K2V2 &V, int vs, const int *s_mem, int 
                 st->err_info[0] = vs; st->err_info[1] = m; st->err_info[2] = m2; st->err_info[3] = s_mem[m]; st->err_info[4] = c1; st->err_info[5] = c2; st->err_info[6] = nzero;
             }
 }
+__device__ __forceinline__ int k2v2_round(const RState *st) { return st->round; }
 __device__ __forceinline__ void k2v2_sizes(const RState *st, int &S, int &go, int &nzero, int &nv0, int &ncross)
 {
     S = st->S; go = st->go && !r2_halted(st); nzero = st->nzero; nv0 = st->nv; ncross = st->ncross;
@@ -2631,6 +2649,7 @@ struct bslv_poly {
     int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
     int r2_min_cuts = 0;              // rounds go on while they hold at least this many cuts on average (debug_set key 8; 0: until the rounds hold one cut each; -1: always)
     long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0, r2_late_left = 0, r2_torn_reads = 0;
+    long r2_fb_reason[5] = {0, 0, 0, 0, 0}, r2_fb_nm[20] = {0};     // fallback prunes by cause and by log2 of the member count (BSLV_R2_REPORT)
     int batch_mode = 1;               // 0: one cut at a time, 1: rounds of independent cuts
     long rounds_run = 0, conf_pairs = 0, conf_cuts = 0;
     int dense_streak = 0, dense_skip = 0;   // adaptive skipping of the conflict pass (apply_cuts_rounds)
@@ -3483,6 +3502,12 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
 void bslv_poly_destroy(bslv_poly *h)
 {
     if (!h) return;
+    if (getenv("BSLV_R2_REPORT") && h->r2_fallback_prunes) {
+        fprintf(stderr, "r2: %ld prunes of rounds went through the multi-kernel path: %ld members > %d, %ld pair bitmap, %ld hash table, %ld bit matrix | members by power of two:", h->r2_fallback_prunes,
+                h->r2_fb_reason[1], K2_MAXNM, h->r2_fb_reason[2], h->r2_fb_reason[3], h->r2_fb_reason[4]);
+        for (int k = 0; k < 20; k++) if (h->r2_fb_nm[k]) fprintf(stderr, " 2^%d: %ld", k, h->r2_fb_nm[k]);
+        fprintf(stderr, "\n");
+    }
     if (getenv("BSLV_TIMING"))
         fprintf(stderr, "poly timing: add_cuts %.1f ms | hot_begin %.1f, sequences %.1f (%ld cuts, %.1f us each), hot_end %.1f ms | %ld hot chunks, %.0f elements, %.0f edges on average\n", h->tm_add_cuts,
                 h->tm_hot_begin, h->tm_seq, h->tm_seq_cuts, h->tm_seq_cuts ? h->tm_seq * 1e3 / h->tm_seq_cuts : 0.0, h->tm_hot_end, h->hot_chunks,
