@@ -61,6 +61,7 @@ struct bslv_benson {
     // the last fam_batches outer iterations: fam_mode 0 newest cuts first, 1 pseudo-random, 2 far apart (farthest-point sampling on
     // the cuts' normals), so that the families of one batch act on different neighbourhoods of the polyhedron
     int fam_mode = 3, fam_batches = 1, fam_cap = 0;
+    long fam_fallbacks = 0;                           // batches that one family would have filled: taken newest first
     double facet_z0 = getenv("BSLV_FACET_Z0") ? atof(getenv("BSLV_FACET_Z0")) : (double)INFINITY;
     std::deque<int> batch_f0;                         // first dual slot of each of the last outer iterations
     std::vector<double> facet_normal;                 // q per dual slot (zeros where unknown)
@@ -355,6 +356,13 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
             const int cap = h->fam_cap > 0 ? h->fam_cap : INT_MAX;
             for (int t : ord) { if (have >= max_batch) break; chosen.push_back(cand[t]); have += std::min(cap, counts[cand[t] - f_lo]); full += counts[cand[t] - f_lo]; }
         }
+        // A batch that ONE family fills (the pool serves few LPs at a time -- S-degenerate: 64 -- or the family is huge) has nothing of
+        // what the rule is for: it would take the first slots of the shallowest cut's children, step after step.  Such a batch is
+        // taken newest first, as rounds 1-2 did (S-degenerate q = 10, three steps: 17 -> 134 LPs/s; BSLV_FAM_FALLBACK=0: never)
+        static const bool fam_fallback = !(getenv("BSLV_FAM_FALLBACK") && atoi(getenv("BSLV_FAM_FALLBACK")) == 0);
+        const bool one_family = fam_fallback && !chosen.empty() && counts[chosen[0] - f_lo] >= max_batch;
+        if (one_family) h->fam_fallbacks++;
+        else {
         // (with a cap on the children of one cut the device hands over the whole families and the host thins them out)
         const int fetch = h->fam_cap > 0 ? (int)std::min<long long>(std::max<long long>(full, 1), 16LL * max_batch) : max_batch;
         std::vector<int> idx(fetch), ideal(fetch), parent(fetch);
@@ -389,6 +397,7 @@ int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, in
         h->unprocessed_left = total - nkept;
         // (a window that held only directions: the next call sees them marked)
         return deal_batch(h, B, rank, world, n_local, n_total);
+        }
     }
     for (;;) {
         const int pol = h->policy == 5 ? 3 : h->policy >= 3 ? 1 : h->policy;
