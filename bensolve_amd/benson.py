@@ -173,6 +173,16 @@ class BensonEngine:
         check(self.lib.bslv_benson_start_stats(self.h, ctypes.byref(a), ctypes.byref(b)))
         return dict(root=a.value, nearest=b.value)
 
+    def set_defer(self, min_cuts):
+        self.lib.bslv_benson_set_defer.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        check(self.lib.bslv_benson_set_defer(self.h, int(min_cuts)))
+
+    def defer_stats(self):
+        out = (ctypes.c_long * 4)()
+        self.lib.bslv_benson_defer_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        check(self.lib.bslv_benson_defer_stats(self.h, out))
+        return dict(handed_back=out[0], waiting=out[1], flushes=out[2], one_family_batches=out[3])
+
     def run(self, max_batch, max_steps=None):
         """run to termination (poly__get_vrtx returns 'none left', bslv_algs.c:1032-1035)"""
         steps = 0

@@ -61,6 +61,13 @@ struct bslv_benson {
     // the last fam_batches outer iterations: fam_mode 0 newest cuts first, 1 pseudo-random, 2 far apart (farthest-point sampling on
     // the cuts' normals), so that the families of one batch act on different neighbourhoods of the polyhedron
     int fam_mode = 3, fam_batches = 1, fam_cap = 0;
+    // cuts that bslv_poly_add_cuts handed back (thin rounds at the end of a chunk, bslv_poly_set_defer): kept with what their
+    // bookkeeping needs and handed in again IN FRONT of the next batch's cuts; collect applies them all before it reports
+    // "nothing left".  Identical on every rank (the cut phase is replicated); `slot` is the tableau of the LP on its owner.
+    struct Deferred { std::vector<double> ys; double z; int owner, slot, front; };
+    std::vector<Deferred> deferred;
+    int defer_thr = getenv("BSLV_DEFER") ? std::max(0, atoi(getenv("BSLV_DEFER"))) : 0, defer_max = 512;
+    long tot_deferred = 0, defer_flushes = 0;
     long fam_fallbacks = 0;                           // batches that one family would have filled: taken newest first
     double facet_z0 = getenv("BSLV_FACET_Z0") ? atof(getenv("BSLV_FACET_Z0")) : (double)INFINITY;
     std::deque<int> batch_f0;                         // first dual slot of each of the last outer iterations
@@ -286,7 +293,21 @@ int bslv_benson_collect(bslv_benson *h, int max_batch, int rank, int world, int 
 {
     return bslv_benson_collect_ctx(h, 0, max_batch, rank, world, n_local, n_total);
 }
+static int collect_impl(bslv_benson *h, int ctx, int max_batch, int rank, int world, int *n_local, int *n_total);
+int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *records, long *stats);
 int bslv_benson_collect_ctx(bslv_benson *h, int ctx, int max_batch, int rank, int world, int *n_local, int *n_total)
+{
+    int rc = collect_impl(h, ctx, max_batch, rank, world, n_local, n_total);
+    // "nothing left" is only true once the cuts that were handed back (bslv_benson::deferred) are applied: they may create vertices
+    for (int guard = 0; !rc && *n_total == 0 && !h->deferred.empty() && guard < 64; guard++) {
+        long st[5];
+        h->defer_flushes++;
+        if ((rc = bslv_benson_apply_ctx(h, ctx, 0, nullptr, st))) return rc;
+        rc = collect_impl(h, ctx, max_batch, rank, world, n_local, n_total);
+    }
+    return rc;
+}
+static int collect_impl(bslv_benson *h, int ctx, int max_batch, int rank, int world, int *n_local, int *n_total)
 {
     if (!h || !h->started || max_batch < 1 || world < 1 || rank < 0 || rank >= world || !n_local || !n_total || ctx < 0 || ctx > 1) {
         set_error("bslv_benson_collect: bad argument / not started");
@@ -760,6 +781,14 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     std::vector<double> cuts;
     std::unordered_set<std::string> dedupe;
     long nfail = 0, nduplicate = 0, nstatus[5] = {0, 0, 0, 0, 0};
+    auto key_of = [&](const double *ys) {
+        double sc = 1.0;
+        for (int kk = 0; kk < q; kk++) sc = std::max(sc, std::fabs(ys[kk]));
+        std::string key((size_t)q * sizeof(long long), '\0');
+        for (int kk = 0; kk < q; kk++) { long long v = std::llround(ys[kk] / sc * 1e11); memcpy(&key[(size_t)kk * sizeof(long long)], &v, sizeof v); }
+        return key;
+    };
+    for (const auto &dfr : h->deferred) dedupe.insert(key_of(dfr.ys.data()));       // (a new copy of a cut that is waiting is a duplicate too)
     for (int k : order) {
         const double *rec = records + (size_t)k * RL;
         if ((int)rec[1] != BSLV_LP_OPTIMAL) { nfail++; nstatus[std::min(std::max((int)rec[1], 0), 4)]++; continue; }
@@ -768,11 +797,7 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
             // a cut already in this batch has no violating vertex once the first copy is applied (the reference's
             // poly__add_vrtx returns EXIT_FAILURE for it, bslv_poly.c:130-136); it is dropped here, on the host, instead
             // of paying a classification pass.  Key: coordinates relative to max(1,|y*|), rounded to 1e-11.
-            double sc = 1.0;
-            for (int kk = 0; kk < q; kk++) sc = std::max(sc, std::fabs(rec[4 + kk]));
-            std::string key((size_t)q * sizeof(long long), '\0');
-            for (int kk = 0; kk < q; kk++) { long long v = std::llround(rec[4 + kk] / sc * 1e11); memcpy(&key[(size_t)kk * sizeof(long long)], &v, sizeof v); }
-            if (!dedupe.insert(key).second) { nduplicate++; continue; }
+            if (!dedupe.insert(key_of(rec + 4)).second) { nduplicate++; continue; }
             cuts.insert(cuts.end(), rec + 4, rec + 4 + q); cut_src.push_back(k);
         }
         else confirmed.push_back((int)rec[0]);                                                           // :1074-1079
@@ -793,9 +818,28 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
         if (!ids.empty() && (rc = bslv_lpq_get_primal(h->lp, (int)ids.size(), slots.data(), h->M, h->n, X.data()))) return rc;
         for (size_t k = 0; k < ids.size(); k++) h->primg_p[ids[k]].assign(X.begin() + k * h->n, X.begin() + (k + 1) * h->n);
     }
-    const int ncut = (int)cut_src.size();
+    // the cuts of this call: those handed back by earlier calls first, then the new ones
+    struct CutInfo { double z; int owner, slot, front, src; };
+    std::vector<CutInfo> info;
+    {
+        std::vector<double> all;
+        all.reserve(h->deferred.size() * q + cuts.size());
+        for (const auto &dfr : h->deferred) { all.insert(all.end(), dfr.ys.begin(), dfr.ys.end()); info.push_back(CutInfo{dfr.z, dfr.owner, dfr.slot, dfr.front, -1}); }
+        for (size_t c = 0; c < cut_src.size(); c++) {
+            const double *rec = records + (size_t)cut_src[c] * RL;
+            info.push_back(CutInfo{rec[3], (int)rec[4 + q], -1, 0, (int)rec[0]});
+        }
+        all.insert(all.end(), cuts.begin(), cuts.end());
+        cuts.swap(all);
+        h->deferred.clear();
+    }
+    const int ncut = (int)info.size();
     std::vector<int> prc(ncut, 0);
     const int f0 = bslv_poly_ndual(h->poly);
+    // thin rounds hand their cuts back only while a later call is certain (new LPs in this one) and the backlog is small
+    // (and the batch is large -- small batches have nothing but thin rounds; every waiting cut also holds a tableau of the pool)
+    const int thr = (nrec >= 512 && !h->mark_at_collect && ncut - (int)cut_src.size() < std::min(h->defer_max, h->pool_slots / 8)) ? h->defer_thr : 0;
+    if ((rc = bslv_poly_set_defer(h->poly, thr))) return rc;
     if (ncut && (rc = bslv_poly_add_cuts(h->poly, ncut, cuts.data(), nullptr, prc.data()))) return rc;
     // bookkeeping: facet ids f0.. were assigned in this order on every rank
     std::lock_guard<std::mutex> lk(h->slot_mu);
@@ -803,8 +847,8 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     h->batch_f0.push_back(f0);
     while (h->batch_f0.size() > 64) h->batch_f0.pop_front();
     h->facet_normal.resize((size_t)(f0 + ncut) * q, 0.0);
-    h->facet_z.resize((size_t)(f0 + ncut), h->facet_z0);      // (facets whose depth is not known -- those of the start -- count as the deepest)
-    for (int c = 0; c < ncut; c++) h->facet_z[f0 + c] = records[(size_t)cut_src[c] * RL + 3];
+    h->facet_z.resize((size_t)(f0 + ncut), h->facet_z0);
+    for (int c = 0; c < ncut; c++) h->facet_z[f0 + c] = info[c].z;
     for (int c = 0; c < ncut; c++) {                  // normal of the cut y*: (y*_1 .. y*_{q-1}, 1 - c.y*) (lowerV2upperH, bslv_algs.c:287-305), scaled to length 1
         double *nn = &h->facet_normal[(size_t)(f0 + c) * q];
         const double *ys = &cuts[(size_t)c * q];
@@ -815,44 +859,47 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
         len = std::sqrt(std::max(len, 1e-300));
         for (int k = 0; k < q; k++) nn[k] /= len;
     }
-    std::unordered_map<int, int> front_of_src;
     if (h->policy == 4) {
         h->facet_front.resize(f0 + ncut, -1);
+        std::unordered_map<int, int> front_of_src;
         for (size_t k = 0; k < B.b_idx.size() && k < B.b_front.size(); k++) front_of_src[B.b_idx[k]] = B.b_front[k];
+        for (int c = 0; c < ncut; c++) if (info[c].src >= 0) { auto it = front_of_src.find(info[c].src); info[c].front = it != front_of_src.end() ? it->second : 0; }
     }
-    long applied = 0;
+    long applied = 0, handed_back = 0;
     // local slot of a record: position in this rank's shard
     std::unordered_map<int, int> slot_of_src;
     for (size_t k = 0; k < B.l_pos.size(); k++) slot_of_src[B.b_idx[B.l_pos[k]]] = B.l_slot[k];
     for (int c = 0; c < ncut; c++) {
-        const double *rec = records + (size_t)cut_src[c] * RL;
-        const int owner = (int)rec[4 + q], f = f0 + c;
-        h->facet_owner[f] = owner;
-        if (h->policy == 4) {
-            auto it = front_of_src.find((int)rec[0]);
-            h->facet_front[f] = it != front_of_src.end() ? it->second : 0;
+        CutInfo &ci = info[c];
+        const int f = f0 + c;
+        h->facet_owner[f] = ci.owner;
+        if (h->policy == 4) h->facet_front[f] = ci.front;
+        if (ci.src >= 0 && ci.owner == h->rank) {       // a new cut of this rank: the tableau of its LP
+            auto it = slot_of_src.find(ci.src);
+            if (it != slot_of_src.end()) { ci.slot = it->second; slot_of_src.erase(it); }
         }
-        if (prc[c] == 0) applied++;
-        if (owner == h->rank) {
-            auto it = slot_of_src.find((int)rec[0]);
-            if (it != slot_of_src.end()) {
-                if (prc[c] == 0 && h->want_primg) {                                 // (u, w) of the cut (:1066-1071)
+        if (prc[c] == 0) {
+            applied++;
+            if (ci.slot >= 0) {
+                if (h->want_primg) {                                 // (u, w) of the cut (:1066-1071)
                     std::vector<double> uw(h->m + q);
-                    const int sl = it->second;
+                    const int sl = ci.slot;
                     if ((rc = bslv_lpq_get_dual(h->lp, 1, &sl, 0, h->m + q, uw.data()))) return rc;
                     h->primg_d[f] = uw;
                 }
-                if (prc[c] == 0) { h->facet_slot[f] = it->second; h->parents.emplace_back(f, it->second); }
-                else h->free_slots.push_back(it->second);
-                slot_of_src.erase(it);
+                h->facet_slot[f] = ci.slot; h->parents.emplace_back(f, ci.slot);
             }
-        }
+        } else if (prc[c] == 2) {                        // handed back: its tableau stays reserved
+            handed_back++;
+            h->deferred.push_back(bslv_benson::Deferred{std::vector<double>(&cuts[(size_t)c * q], &cuts[(size_t)(c + 1) * q]), ci.z, ci.owner, ci.slot, ci.front});
+        } else if (ci.slot >= 0) h->free_slots.push_back(ci.slot);
     }
+    h->tot_deferred += handed_back;
     for (auto &kv : slot_of_src) h->free_slots.push_back(kv.second);    // confirmed vertices: tableau not needed again
     B.l_pos.clear(); B.l_slot.clear();
     h->tot_lps += nrec;
     h->tot_cuts += applied;
-    if (stats) { stats[0] = nrec; stats[1] = applied; stats[2] = ncut - applied + nduplicate; stats[3] = (long)confirmed.size(); stats[4] = nfail; }
+    if (stats) { stats[0] = nrec; stats[1] = applied; stats[2] = ncut - applied - handed_back + nduplicate; stats[3] = (long)confirmed.size(); stats[4] = nfail; }
     return 0;
 }
 
@@ -896,6 +943,21 @@ int bslv_benson_set_families(bslv_benson *h, int mode, int batches)
 {
     if (!h || mode < 0 || mode > 5 || batches < 1 || batches > 64) return BSLV_E_ARG;
     h->fam_mode = mode; h->fam_batches = batches;
+    return 0;
+}
+// min_cuts > 0: the polyhedron engine may hand the cuts of thin rounds back (bslv_poly_set_defer); they go in again with the next batch.
+int bslv_benson_set_defer(bslv_benson *h, int min_cuts)
+{
+    if (!h || min_cuts < 0) return BSLV_E_ARG;
+    h->defer_thr = min_cuts;
+    return 0;
+}
+// [0] cuts handed back so far (a cut counts every time), [1] cuts waiting now, [2] times collect had to apply the waiting cuts before it
+// could answer, [3] batches that one family would have filled (taken newest first)
+int bslv_benson_defer_stats(const bslv_benson *h, long out[4])
+{
+    if (!h || !out) return BSLV_E_ARG;
+    out[0] = h->tot_deferred; out[1] = (long)h->deferred.size(); out[2] = h->defer_flushes; out[3] = h->fam_fallbacks;
     return 0;
 }
 int bslv_benson_set_fronts(bslv_benson *h, int nfronts, int sib_cap)

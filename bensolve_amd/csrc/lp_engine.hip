@@ -37,7 +37,10 @@ constexpr int MODE_NONE = 0, MODE_PIVOT = 1, MODE_REFRESH = 2;
 constexpr int PF_PERT = 1, PF_PRIMAL = 2, PF_PERT_PENDING = 4, PF_USES_SHIFT = 8;   // BatchView::pflags
 constexpr int STALL_LIMIT = 3;         // consecutive degenerate pivots (dual step <= 1e-11) after which the costs are perturbed
 constexpr int PERT_MAX_USES = 3;       // perturbations per solve
-constexpr int KP = 6;                  // pivots selected between two passes over the tableau (delayed update; 4: 3.4 ms, 6: 3.0, 8: 3.1 ms per S-mid batch)
+#ifndef BSLV_KP
+#define BSLV_KP 6
+#endif
+constexpr int KP = BSLV_KP;                  // pivots selected between two passes over the tableau (delayed update; 4: 3.4 ms, 6: 3.0, 8: 3.1 ms per S-mid batch)
 constexpr int REFRESH_AFTER = 32;      // pivots of one solve after which optimality is only declared on a recomputed beta
 constexpr double TOL_BND = 1e-9, TOL_DJ = 1e-9, TOL_PIV = 1e-9;
 constexpr double BIG = 1e7;   // artificial bound for dual-infeasible free columns

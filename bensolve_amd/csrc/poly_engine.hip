@@ -2646,6 +2646,10 @@ struct bslv_poly {
     long r2_spec_void = 0;            // rounds that were queued ahead and found the device halted (bslv_poly_rounds2_stats)
     bool r2_mis = true;               // rounds take a MAXIMAL independent set from a conflict matrix of the chunk (round 3); BSLV_R2_MIS=0 / debug_set key 11: the local minima of one random order (round 2)
     int chunk_cuts = 1024;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
+    int r2_defer = 0;                 // rounds of a chunk stop when one holds fewer cuts than this; what is left is handed BACK to the caller (rc 2) -- see bslv_poly_set_defer
+    bool r2_deferred = false;         // (the last run_rounds2 stopped for that reason)
+    long r2_deferred_cuts = 0, r2_doomed = 0;
+    bool r2_defer_mark = !(getenv("BSLV_DEFER_MARK") && atoi(getenv("BSLV_DEFER_MARK")) == 0);   // elements a handed-back cut will remove are marked processed
     int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
     int r2_min_cuts = 0;              // rounds go on while they hold at least this many cuts on average (debug_set key 8; 0: until the rounds hold one cut each; -1: always)
     long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0, r2_late_left = 0, r2_torn_reads = 0;
@@ -3970,6 +3974,15 @@ int bslv_poly_set_batch_mode(bslv_poly *h, int mode)
     return 0;
 }
 long bslv_poly_rounds_run(const bslv_poly *h) { return h ? h->rounds_run : 0; }
+// Rounds of a chunk end when one holds fewer than min_cuts cuts (0: never -- every cut handed in is applied or found redundant);
+// bslv_poly_add_cuts then reports the cuts still alive with rc 2: NOT applied, their dual slots stay behind unused like those of
+// redundant cuts, the caller hands the same halfspaces in again with a later batch (bslv_benson_apply does).
+int bslv_poly_set_defer(bslv_poly *h, int min_cuts)
+{
+    if (!h || min_cuts < 0) return BSLV_E_ARG;
+    h->r2_defer = min_cuts;
+    return 0;
+}
 int bslv_poly_debug_set(bslv_poly *h, int key, long value)
 {
     if (!h) return BSLV_E_ARG;
@@ -3986,6 +3999,7 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 12: h->r2_spec = value != 0; return 0;                           /* rounds queued one ahead of the host (1) / mailbox read before every round (0) */
     case 11: h->r2_mis = value != 0; return 0;                            /* rounds: maximal independent set from the conflict matrix (1) / local minima of one order (0) */
     case 9: g_k1_mfma = value != 0; return 0;                            /* incidence kernel K1 on the matrix pipe from 16 halfspaces on (1) or the scalar kernel (0, default); process-wide */
+    case 14: h->r2_defer = (int)std::max(0L, value); return 0;           /* see bslv_poly_set_defer */
     case 8: h->r2_min_cuts = (int)std::max(-1L, value); return 0;        /* rounds go on while they average at least this many cuts (0: until every round holds one cut, -1: always) */
     case 5: h->member_lists = value != 0; return 0;                     /* edges of large facets confirmed through member lists (1) or against all elements (0) */           /* facets from this size on confirm edges through the facet-major member lists (4096) */
     default: return BSLV_E_ARG;

@@ -160,6 +160,11 @@ long bslv_poly_rounds2_torn_reads(const bslv_poly *h);
  * prune (64 forces the multi-kernel prune), 1 speculative launch on/off, 2 hot mode on/off, 3 CROSS_UB, 4 size of a new facet
  * from which the multi-kernel prune builds facet-major member lists (default 4096), 5 member lists on/off, 6 device-selected
  * rounds of independent cuts inside a hot chunk on/off, 7 cuts per chunk (32..4096, default 512) */
+/* bslv_poly_add_cuts may hand cuts BACK (rc 2: not applied, dual slot left unused) when the rounds of a chunk get thinner than
+ * min_cuts cuts -- the tail of a chunk is its cliques, one cut each per pass over the polyhedron; the caller hands the same
+ * halfspaces in again with its next batch (phase2_primal has no counterpart: bslv_algs.c:1041-1080 applies one cut per LP).
+ * 0 (default): every cut handed in is applied or found redundant, as poly__add_vrtx does (bslv_poly.c:104-151). */
+int  bslv_poly_set_defer(bslv_poly *h, int min_cuts);
 int  bslv_poly_debug_set(bslv_poly *h, int key, long value);
 /* rounds of independent cuts chosen and applied on the device inside a hot chunk (debug_set key 6 switches them off, key 7 sets
  * the number of cuts classified and applied together): out[0] rounds, [1] cuts applied in them, [2] chunks, [3] prunes that took
@@ -264,6 +269,13 @@ int  bslv_benson_set_fronts(bslv_benson *h, int nfronts, int sib_cap);
  * policy 6: whole families -- all unprocessed children of a cut -- of parents chosen among the cuts of the last `batches` outer
  * iterations: mode 0 newest cuts first, 1 pseudo-random, 2 far apart (farthest-point sampling on the cuts' normals) */
 int  bslv_benson_set_families(bslv_benson *h, int mode, int batches);
+/* Thin rounds at the end of a chunk of cuts (its cliques, one cut each per pass over the polyhedron) may hand their cuts back
+ * (bslv_poly_set_defer(min_cuts)); bslv_benson_apply keeps them and hands them in again in front of the next batch's cuts,
+ * bslv_benson_collect applies whatever is waiting before it reports "nothing left".  0 = off (every cut of a batch is applied
+ * in its own outer iteration, as bslv_algs.c:1041-1080 does).  stats: [0] handed back so far, [1] waiting, [2] flushes by
+ * collect, [3] batches that one family would have filled (taken newest first). */
+int  bslv_benson_set_defer(bslv_benson *h, int min_cuts);
+int  bslv_benson_defer_stats(const bslv_benson *h, long out[4]);
 /* tuning hooks (no counterpart in the reference): the caller chooses the batch itself -- elements with their coordinates and
  * parent facets as bslv_poly_unprocessed2 returns them -- and reads, per LP of this rank's last solve_local, the warm-start slot
  * (0 = root tableau), the pivots and the generation of the new slot; returns the number of entries written */

@@ -98,6 +98,32 @@ def test_s_small_complete_run_matches_oracle():
     assert len(exp["X"]) > 5000 and paths["single_cuts"] + r2["cuts"] > 100 and r2["rounds"] > 0
 
 
+def test_cuts_handed_back_by_thin_rounds_are_applied_later():
+    """bslv_benson_set_defer: the rounds of a chunk may stop when they get thin; the cuts still alive come back with rc 2, wait
+    in the driver (their tableaux reserved, the elements they will remove marked as processed) and go in again in front of the
+    next batch; collect applies what is waiting before it reports 'nothing left'.  The run must end on the same upper image as
+    the sequential CPU oracle, with nothing waiting, and the path must have been taken."""
+    prob = synth.CONFIGS["S-small"]()
+    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=1e-9)
+    assert rc == 0
+    fp.dual_adjacency()
+    exp = ph.canonical(fp.dump(), decimals=6)
+    fp.close()
+    eng = BensonEngine(prob, eps=1e-9, pool_slots=4 * 2048 + 64)
+    eng.set_defer(6)
+    assert eng.start() == 0
+    eng.run(2048)
+    ds = eng.defer_stats()
+    eng.poly_call("dual_adjacency")
+    got = ph.canonical(eng.poly_dump(), decimals=6)
+    health = eng.poly_call("rounds2_health")
+    eng.close()
+    assert ds["handed_back"] > 0 and ds["waiting"] == 0, ds
+    assert health["late_left"] == 0, health
+    # (the allow-list of test_s_small_complete_run_matches_oracle: another cut order at eps = POLY_EPS)
+    ph.assert_benson_results_agree(got, exp, tol=1e-6, allow_sliver=("S-small to termination with cuts handed back: different cut order at eps = POLY_EPS", 24))
+
+
 import os
 import json
 
