@@ -171,6 +171,7 @@ def main():
     phase_ms[:] = [0.0, 0.0, 0.0]
     rounds0 = eng.poly_call("rounds_run")
     ps0 = eng.poly_call("path_stats")
+    r2s0 = eng.poly_call("rounds2_stats")
     nv0 = eng.poly_call("counts")["new_vertices"]
     pt0 = eng.poly_call("counts")["pair_tests"]
     lps = cuts = pivots = lockstep = redundant = confirmed = passes = 0
@@ -198,7 +199,7 @@ def main():
     eng.lp_call("set_profile", False)
     # the counters of the timed region, before anything else runs on this engine
     snap = {"counts": eng.poly_call("counts"), "rounds_run": eng.poly_call("rounds_run"), "path_stats": eng.poly_call("path_stats"),
-            "health": eng.poly_call("rounds2_health"), "starts": eng.start_stats(), "totals": eng.totals()}
+            "health": eng.poly_call("rounds2_health"), "starts": eng.start_stats(), "totals": eng.totals(), "r2": eng.poly_call("rounds2_stats"), "defer": eng.defer_stats()}
     snap["live"] = int(eng.poly_dump()["pu"].sum()) if snap["counts"]["nprimal"] < 5_000_000 else -1
     phase_timed = list(phase_ms)         # (a copy: one_step() keeps adding to phase_ms if the run goes on below)
     # Everything the headline needs is measured.  Two more figures for the reader, outside the timed region (rank 0, one GPU):
@@ -288,6 +289,8 @@ def main():
                      "single_cut_pipeline_cuts": ps["single_cuts"] - ps0["single_cuts"], "hot_chunks": ps["hot_chunks"] - ps0["hot_chunks"],
                      "pair_tests_per_sec": round(pair_tests / dt, 1), "reference_pair_tests_per_sec_1core": 6.9e6,
                      "mailbox": snap["health"],
+                     "multi_kernel_prunes": snap["r2"]["fallback_prunes"] - r2s0["fallback_prunes"],
+                     "cuts_handed_back": snap["defer"]["handed_back"], "cuts_waiting_at_end": snap["defer"]["waiting"], "one_family_batches": snap["defer"]["one_family_batches"],
                      "note": "a round applies a maximal set of mutually independent cuts of the chunk (<= 1024 cuts) in the passes of one cut: ~250 us of dependent small launches, latency-bound (profiles/r03_cut_phase_counters.json: 64-92 % of wave cycles waiting)"}
 
     cpu = None
