@@ -2930,7 +2930,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
         // facet, so that confirming an edge scans one facet's elements instead of all nm
         const size_t lds_tiled = ((size_t)PTI * W + (size_t)W * (PB + PTI) + 4 * (size_t)W) * sizeof(unsigned long long);
         const int ngroups = (nm - 1 + PTI - 1) / PTI;
-        const bool tiled = nm >= h->fm_min && h->d > 1 && lds_tiled <= 48 * 1024 && ngroups <= 65535;
+        const bool tiled = nm >= h->fm_min && h->d > 1 && lds_tiled <= 48 * 1024;      // (more than 65535 row groups: several launches, below)
         const bool fm = tiled && h->member_lists && len_ub <= (1ll << 30);
         if (tiled) {
             if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(hipMalloc(&h->nzlist, (nc + 1) * sizeof(int))); h->nzcap = nc; }
@@ -2965,10 +2965,10 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
                 HIP_TRY(hipMemsetAsync(h->bsum, 0, (size_t)nbp * sizeof(Tri), s));          // the blocks of the other ranks: no pair
                 h->n_sharded++;
             }
-            if (g1 > g0)
-            hipLaunchKernelGGL(k_pair_flags_tiled, dim3((unsigned)((nm - 1 + PB - 1) / PB), (unsigned)(g1 - g0)), dim3(PB), lds_tiled, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
-                               fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr,
-                               h->nzlist, h->nzlist + h->nzcap, g0);
+            for (int ga = g0; ga < g1; ga += 65535)          // (gridDim.y holds 65535 row groups: facets of more than 65535 * PTI elements take several launches)
+                hipLaunchKernelGGL(k_pair_flags_tiled, dim3((unsigned)((nm - 1 + PB - 1) / PB), (unsigned)std::min(65535, g1 - ga)), dim3(PB), lds_tiled, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
+                                   fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr,
+                                   h->nzlist, h->nzlist + h->nzcap, ga);
         }
         else {
             // one-dimensional grid of pair blocks: at most 2^32 work-items (the runtime wraps a larger grid silently)
