@@ -201,6 +201,7 @@ def main():
     snap = {"counts": eng.poly_call("counts"), "rounds_run": eng.poly_call("rounds_run"), "path_stats": eng.poly_call("path_stats"),
             "health": eng.poly_call("rounds2_health"), "starts": eng.start_stats(), "totals": eng.totals(), "r2": eng.poly_call("rounds2_stats"), "defer": eng.defer_stats()}
     snap["live"] = int(eng.poly_dump()["pu"].sum()) if snap["counts"]["nprimal"] < 5_000_000 else -1
+    if rank == 0: print("bench: timed region done (%d steps, %.3f s)" % (args.steps, dt), file=sys.stderr, flush=True)
     phase_timed = list(phase_ms)         # (a copy: one_step() keeps adding to phase_ms if the run goes on below)
     # Everything the headline needs is measured.  Two more figures for the reader, outside the timed region (rank 0, one GPU):
     #  * long_window: the SAME run continued to 5x the steps -- S-mid never terminates, the polyhedron keeps growing, and the rate
@@ -216,6 +217,7 @@ def main():
             l2 += s["lps"]; c2 += s["cuts"]; f2 += s.get("confirmed", 0)
         sync()
         dtl = time.perf_counter() - tl
+        print("bench: long window done (%d more steps, %.3f s)" % (extra, dtl), file=sys.stderr, flush=True)
         long_window = {"steps": args.steps + extra, "lps_per_sec": round((lps + l2) / (dt + dtl), 1), "useful_lps_per_sec": round((cuts + confirmed + c2 + f2) / (dt + dtl), 1),
                        "continuation_only": {"lps_per_sec": round(l2 / dtl, 1), "useful_lps_per_sec": round((c2 + f2) / dtl, 1)},
                        "note": "the timed region plus 4x as many steps of the same run (not part of `value`)"}
@@ -329,6 +331,7 @@ def main():
                "every_lp_useful": True}
         if args.workload == "S-mid" and not args.policy and not args.no_long_window:
             # the batch selection rule of rounds 1-2 on a fresh engine, same ramp / warm-up / steps: what BENCH_r01 / r02 measured
+            print("bench: CPU baseline done; rounds-1-2 rule on a fresh engine ...", file=sys.stderr, flush=True)
             e3 = BensonEngine(prob, eps=1e-7, pool_slots=pool_slots)
             e3.set_policy(1)
             e3.poly_call("debug_set", 11, 0); e3.poly_call("debug_set", 7, 512)      # (rounds by local minima, chunks of 512: round 2's cut phase)
@@ -346,11 +349,13 @@ def main():
                 l3 += s3["lps"]; c3 += s3["cuts"] + s3["confirmed"]
             torch.cuda.synchronize(); t3 = time.perf_counter() - t3
             e3.close()
+            print("bench: rounds-1-2 rule done", file=sys.stderr, flush=True)
             cpu["policy_newest_first_rounds_of_local_minima"] = {"lps_per_sec": round(l3 / t3, 1), "useful_lps_per_sec": round(c3 / t3, 1), "lps_redundant_frac": round(1 - c3 / max(l3, 1), 4),
                                                                   "note": "rounds 1-2's selection (newest vertices first) and cut phase (local minima of one order, chunks of 512) on a fresh engine over the same window; not part of `value`"}
         if not args.no_pair and args.workload != "S-small":
             # like-for-like pair: S-small to termination on both sides (same problem, same eps, whole phase 2)
             sp = synth.CONFIGS["S-small"]()
+            print("bench: S-small pair ...", file=sys.stderr, flush=True)
             e2 = BensonEngine(sp, eps=1e-7, pool_slots=4 * 2048 + 64)
             e2.start()
             torch.cuda.synchronize(); tg = time.perf_counter()

@@ -21,6 +21,17 @@ void set_error(const char *fmt, ...);
         }                                                                                     \
     } while (0)
 
+// Device memory of the engines starts out as ZEROS.  A fresh process gets zero pages from the driver, a process that has destroyed
+// an engine gets that engine's memory back: without this the two differ (seen as a memory access fault in the third engine of a
+// bench run, never in a test process), and "reproducible bit for bit" would depend on who used the memory before.
+template <class T>
+static inline hipError_t malloc0(T **p, size_t bytes)
+{
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e == hipSuccess && bytes) e = hipMemset((void *)*p, 0, bytes);
+    return e;
+}
+
 constexpr int WAVE = 64;
 
 // wave-level reductions (64 lanes)

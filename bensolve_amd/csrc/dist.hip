@@ -136,8 +136,8 @@ int bslv_dist_allgather(const double *send, double *recv, int count)
             g.send_d = g.recv_d = nullptr;
             g.cap = 0;
             const size_t nc = std::max<size_t>((size_t)count, 4096);
-            HIP_TRY(hipMalloc(&g.send_d, nc * sizeof(double)));
-            HIP_TRY(hipMalloc(&g.recv_d, nc * g.world * sizeof(double)));
+            HIP_TRY(malloc0(&g.send_d, nc * sizeof(double)));
+            HIP_TRY(malloc0(&g.recv_d, nc * g.world * sizeof(double)));
             g.cap = nc;
         }
         HIP_TRY(hipMemcpyAsync(g.send_d, send, (size_t)count * sizeof(double), hipMemcpyHostToDevice, g.stream));

@@ -897,28 +897,28 @@ static int ensure_batch(bslv_lpq *h, int B)
     if (h->status_h) { (void)hipHostFree(h->status_h); h->status_h = nullptr; }
     if (h->active_h) { (void)hipHostFree(h->active_h); h->active_h = nullptr; }
     h->Bcap = 0;
-    HIP_TRY(hipMalloc(&h->src_d, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->dst_d, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->status_d, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->iters_d, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->mode_d, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->work_d, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->ver_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->src_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->dst_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->status_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->iters_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->mode_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->work_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->ver_d, cap * sizeof(int)));
     size_t vc = (size_t)std::max(1, h->L.vcnt);
-    HIP_TRY(hipMalloc(&h->vlo_d, cap * vc * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->vup_d, cap * vc * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->prow_d, (size_t)cap * KP * h->L.ld * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->desc_d, (size_t)cap * KP * sizeof(PivDesc)));
-    HIP_TRY(hipMalloc(&h->pcol_d, (size_t)cap * KP * h->L.Mp1p * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->dcur_d, (size_t)cap * h->L.ld * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->dper_d, (size_t)cap * h->L.ld * sizeof(double)));
-    HIP_TRY(hipMalloc(&h->pflags_d, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->stall_d, cap * sizeof(int)));
-    if (!h->xstat_d) HIP_TRY(hipMalloc(&h->xstat_d, 8 * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->npend_d, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->flushed_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->vlo_d, cap * vc * sizeof(double)));
+    HIP_TRY(malloc0(&h->vup_d, cap * vc * sizeof(double)));
+    HIP_TRY(malloc0(&h->prow_d, (size_t)cap * KP * h->L.ld * sizeof(double)));
+    HIP_TRY(malloc0(&h->desc_d, (size_t)cap * KP * sizeof(PivDesc)));
+    HIP_TRY(malloc0(&h->pcol_d, (size_t)cap * KP * h->L.Mp1p * sizeof(double)));
+    HIP_TRY(malloc0(&h->dcur_d, (size_t)cap * h->L.ld * sizeof(double)));
+    HIP_TRY(malloc0(&h->dper_d, (size_t)cap * h->L.ld * sizeof(double)));
+    HIP_TRY(malloc0(&h->pflags_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->stall_d, cap * sizeof(int)));
+    if (!h->xstat_d) HIP_TRY(malloc0(&h->xstat_d, 8 * sizeof(int)));
+    HIP_TRY(malloc0(&h->npend_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->flushed_d, cap * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->status_h, cap * sizeof(int)));
-    HIP_TRY(hipMalloc(&h->active_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->active_d, cap * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->active_h, cap * sizeof(int)));
     h->Bcap = cap;
     return 0;
@@ -1024,17 +1024,17 @@ static int raw_create(bslv_lpq **out, int M, int N, const double *A, const doubl
     }
     if (!h->stream && hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
 #define TRYF(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? BSLV_E_NOMEM : BSLV_E_NODEVICE); } } while (0)
-    TRYF(hipMalloc(&L.T, (size_t)pool_slots * L.slotT * sizeof(double)));
-    TRYF(hipMalloc(&L.beta, (size_t)pool_slots * L.Mp1p * sizeof(double)));
-    TRYF(hipMalloc(&L.xN, (size_t)pool_slots * L.ld * sizeof(double)));
-    TRYF(hipMalloc(&L.bh, (size_t)pool_slots * M * sizeof(int)));
-    TRYF(hipMalloc(&L.nh, (size_t)pool_slots * N * sizeof(int)));
-    TRYF(hipMalloc(&L.nstat, (size_t)pool_slots * N * sizeof(int)));
-    TRYF(hipMalloc(&L.pos, (size_t)pool_slots * (M + N) * sizeof(int)));
-    TRYF(hipMalloc(&h->Tstd, L.slotT * sizeof(double)));
-    TRYF(hipMalloc(&h->lb_d, (M + N) * sizeof(double)));
-    TRYF(hipMalloc(&h->ub_d, (M + N) * sizeof(double)));
-    TRYF(hipMalloc(&h->art_d, (M + N)));
+    TRYF(malloc0(&L.T, (size_t)pool_slots * L.slotT * sizeof(double)));
+    TRYF(malloc0(&L.beta, (size_t)pool_slots * L.Mp1p * sizeof(double)));
+    TRYF(malloc0(&L.xN, (size_t)pool_slots * L.ld * sizeof(double)));
+    TRYF(malloc0(&L.bh, (size_t)pool_slots * M * sizeof(int)));
+    TRYF(malloc0(&L.nh, (size_t)pool_slots * N * sizeof(int)));
+    TRYF(malloc0(&L.nstat, (size_t)pool_slots * N * sizeof(int)));
+    TRYF(malloc0(&L.pos, (size_t)pool_slots * (M + N) * sizeof(int)));
+    TRYF(malloc0(&h->Tstd, L.slotT * sizeof(double)));
+    TRYF(malloc0(&h->lb_d, (M + N) * sizeof(double)));
+    TRYF(malloc0(&h->ub_d, (M + N) * sizeof(double)));
+    TRYF(malloc0(&h->art_d, (M + N)));
 #undef TRYF
     L.lb = h->lb_d; L.ub = h->ub_d; L.art = h->art_d;
     {
@@ -1235,13 +1235,13 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     L.objmode = cvals ? 1 : 0; L.cfirst = cfirst; L.ccnt = ccnt;
     if (cvals) {
         const size_t need = (size_t)B * ccnt;
-        if (need > h->cvals_cap) { if (h->cvals_d) (void)hipFree(h->cvals_d); h->cvals_d = nullptr; HIP_TRY(hipMalloc(&h->cvals_d, need * sizeof(double))); h->cvals_cap = need; }
+        if (need > h->cvals_cap) { if (h->cvals_d) (void)hipFree(h->cvals_d); h->cvals_d = nullptr; HIP_TRY(malloc0(&h->cvals_d, need * sizeof(double))); h->cvals_cap = need; }
         HIP_TRY(hipMemcpyAsync(h->cvals_d, cvals, need * sizeof(double), hipMemcpyHostToDevice, s));
     }
     if (const char *e = getenv("BSLV_UPD_GRID")) h->upd_grid = std::max(64, atoi(e));
     {   // one work-list length per lock-step iteration, zeroed here: no reset between iterations
         const int need = L.maxit + 64;
-        if (need > h->nworkcap) { if (h->nwork_d) (void)hipFree(h->nwork_d); h->nwork_d = nullptr; HIP_TRY(hipMalloc(&h->nwork_d, need * sizeof(int))); h->nworkcap = need; }
+        if (need > h->nworkcap) { if (h->nwork_d) (void)hipFree(h->nwork_d); h->nwork_d = nullptr; HIP_TRY(malloc0(&h->nwork_d, need * sizeof(int))); h->nworkcap = need; }
         HIP_TRY(hipMemsetAsync(h->nwork_d, 0, need * sizeof(int), s));
     }
     HIP_TRY(hipMemsetAsync(h->xstat_d, 0, 8 * sizeof(int), s));
@@ -1360,7 +1360,7 @@ static int ensure_out(bslv_lpq *h, size_t n)
     if (n <= h->out_cap) return 0;
     if (h->out_d) (void)hipFree(h->out_d);
     h->out_d = nullptr; h->out_cap = 0;
-    HIP_TRY(hipMalloc(&h->out_d, n * sizeof(double)));
+    HIP_TRY(malloc0(&h->out_d, n * sizeof(double)));
     h->out_cap = n;
     return 0;
 }

@@ -561,7 +561,7 @@ static void launch_classify_batch(hipStream_t s, PolyView P, const double *hps, 
         const int nw = (B + 31) / 32;
         unsigned long long *out2 = nullptr; unsigned *any2 = nullptr; int *tt2 = nullptr;
         if (check) {
-            (void)hipMalloc(&out2, (size_t)nw * P.cap * 8); (void)hipMalloc(&any2, nw * 4); (void)hipMalloc(&tt2, (size_t)2 * (nv + 1) * 4);
+            (void)malloc0(&out2, (size_t)nw * P.cap * 8); (void)malloc0(&any2, nw * 4); (void)malloc0(&tt2, (size_t)2 * (nv + 1) * 4);
             if (anyminus) (void)hipMemcpyAsync(any2, anyminus, nw * 4, hipMemcpyDeviceToDevice, s);
         }
         switch (P.d) {
@@ -2765,7 +2765,7 @@ template <typename T>
 static int grow(T **p, size_t oldn, size_t newn, hipStream_t s, bool zero_tail = false)
 {
     T *q = nullptr;
-    HIP_TRY(hipMalloc(&q, newn * sizeof(T)));
+    HIP_TRY(malloc0(&q, newn * sizeof(T)));
     if (*p && oldn) HIP_TRY(hipMemcpyAsync(q, *p, oldn * sizeof(T), hipMemcpyDeviceToDevice, s));
     if (zero_tail) HIP_TRY(hipMemsetAsync(q + oldn, 0, (newn - oldn) * sizeof(T), s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -2782,7 +2782,7 @@ static int ensure_vcap(bslv_poly *h, int need)
     PolyView &P = h->P;
     // SoA coordinates: re-stride
     double *X = nullptr;
-    HIP_TRY(hipMalloc(&X, (size_t)h->d * ncap * sizeof(double)));
+    HIP_TRY(malloc0(&X, (size_t)h->d * ncap * sizeof(double)));
     for (int k = 0; k < h->d && P.X && h->nv; k++)
         HIP_TRY(hipMemcpyAsync(X + (size_t)k * ncap, P.X + (size_t)k * P.cap, (size_t)h->nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2933,7 +2933,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
         const bool tiled = nm >= h->fm_min && h->d > 1 && lds_tiled <= 48 * 1024;      // (more than 65535 row groups: several launches, below)
         const bool fm = tiled && h->member_lists && len_ub <= (1ll << 30);
         if (tiled) {
-            if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(hipMalloc(&h->nzlist, (nc + 1) * sizeof(int))); h->nzcap = nc; }
+            if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(malloc0(&h->nzlist, (nc + 1) * sizeof(int))); h->nzcap = nc; }
             HIP_TRY(hipMemsetAsync(h->nzlist + h->nzcap, 0, sizeof(int), s));
         }
         if (fm) {
@@ -3461,8 +3461,8 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     h->P.d = dim;
     auto fail = [&](int code) { bslv_poly_destroy(h); return code; };
     if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(BSLV_E_NODEVICE); }
-    if (hipMalloc(&h->totals, 4 * sizeof(Tri)) != hipSuccess || hipMalloc(&h->counters, CRING * CSTRIDE * sizeof(int)) != hipSuccess || hipMalloc(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->k2mail_d, 4 * sizeof(Mail)) != hipSuccess || hipMemset(h->k2mail_d, 0, 4 * sizeof(Mail)) != hipSuccess || hipMalloc(&h->cutdev, CRING * sizeof(CutDev)) != hipSuccess ||
-        hipMalloc(&h->abort_d, 4 * sizeof(int)) != hipSuccess || hipMemset(h->abort_d, 0, 4 * sizeof(int)) != hipSuccess || hipMalloc(&h->zlist, CRING * ZMAX * sizeof(int)) != hipSuccess ||
+    if (malloc0(&h->totals, 4 * sizeof(Tri)) != hipSuccess || malloc0(&h->counters, CRING * CSTRIDE * sizeof(int)) != hipSuccess || malloc0(&h->ne_dev, 4 * sizeof(int)) != hipSuccess || malloc0(&h->k2mail_d, 4 * sizeof(Mail)) != hipSuccess || hipMemset(h->k2mail_d, 0, 4 * sizeof(Mail)) != hipSuccess || malloc0(&h->cutdev, CRING * sizeof(CutDev)) != hipSuccess ||
+        malloc0(&h->abort_d, 4 * sizeof(int)) != hipSuccess || hipMemset(h->abort_d, 0, 4 * sizeof(int)) != hipSuccess || malloc0(&h->zlist, CRING * ZMAX * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->totals_h, 4 * sizeof(Tri)) != hipSuccess || hipHostMalloc(&h->counters_h, 4 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->mail_h, 4 * sizeof(Mail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&h->mail_d, h->mail_h, 0) != hipSuccess ||
@@ -3493,7 +3493,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (const char *e = getenv("BSLV_R2_RULE")) h->r2_rule = atoi(e) ? 1 : 0;
     if (const char *e = getenv("BSLV_CROSS_UB")) h->cross_ub = std::max(0, atoi(e));
     if (const char *e = getenv("BSLV_K2_LDS")) h->k2_lds = (size_t)std::max(64, atoi(e));      // test hook: a small value forces the multi-kernel prune
-    if (getenv("BSLV_K2_DEBUG") && hipMalloc(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
+    if (getenv("BSLV_K2_DEBUG") && malloc0(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
     h->rounds = new RoundsBuf();
     // dual slot 0: "facet at infinity", ideal point (0,..,0,-1)  (bslv_poly.c:83-92)
     std::vector<double> z(dim, 0.0);
@@ -3728,7 +3728,7 @@ int bslv_poly_classify_batch_touch(bslv_poly *h, int B, const double *hps, unsig
     size_t need = (size_t)((B + 31) / 32) * h->P.cap;
     if (need > h->clswcap) { if ((rc = grow(&h->clsw, 0, need, h->stream))) return rc; h->clswcap = need; }
     int *tt = nullptr;
-    HIP_TRY(hipMalloc(&tt, (size_t)2 * std::max(nv, 1) * sizeof(int)));
+    HIP_TRY(malloc0(&tt, (size_t)2 * std::max(nv, 1) * sizeof(int)));
     HIP_TRY(hipMemsetAsync(h->anyminus, 0, ((B + 31) / 32) * sizeof(unsigned), h->stream));
     launch_classify_batch(h->stream, h->P, h->hps_d, B, nv, h->clsw, h->anyminus, tt, tt + nv);
     HIP_TRY(hipGetLastError());
@@ -4097,7 +4097,7 @@ int bslv_k1_mfma_selftest(int dim, int ntiles, unsigned long long seed, long *mi
     for (double &v : X) v = rnd();
     for (double &v : H) v = rnd();
     double *Xd = nullptr, *Hd = nullptr; unsigned long long *md = nullptr;
-    HIP_TRY(hipMalloc(&Xd, X.size() * 8)); HIP_TRY(hipMalloc(&Hd, H.size() * 8)); HIP_TRY(hipMalloc(&md, 8));
+    HIP_TRY(malloc0(&Xd, X.size() * 8)); HIP_TRY(malloc0(&Hd, H.size() * 8)); HIP_TRY(malloc0(&md, 8));
     HIP_TRY(hipMemcpy(Xd, X.data(), X.size() * 8, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(Hd, H.data(), H.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(md, 0, 8));
     const dim3 g((unsigned)(((size_t)ntiles * 64 + 255) / 256)), b(256);
@@ -4259,11 +4259,11 @@ int bslv_poly_dual_adjacency(bslv_poly *h)
     int2 *out_d = nullptr;
     auto cleanup = [&]() { for (void *p : {(void *)ids_d, (void *)flen_d, (void *)fpool_d, (void *)foff_d, (void *)live_d, (void *)out_d}) if (p) (void)hipFree(p); };
 #define TRYC(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s failed: %s", #e, hipGetErrorString(_e)); cleanup(); return BSLV_E_NODEVICE; } } while (0)
-    TRYC(hipMalloc(&ids_d, nm * sizeof(int)));
-    TRYC(hipMalloc(&flen_d, nf * sizeof(int)));
-    TRYC(hipMalloc(&foff_d, (nf + 1) * sizeof(unsigned)));
-    TRYC(hipMalloc(&fpool_d, fpool.size() * sizeof(int)));
-    TRYC(hipMalloc(&live_d, nf));
+    TRYC(malloc0(&ids_d, nm * sizeof(int)));
+    TRYC(malloc0(&flen_d, nf * sizeof(int)));
+    TRYC(malloc0(&foff_d, (nf + 1) * sizeof(unsigned)));
+    TRYC(malloc0(&fpool_d, fpool.size() * sizeof(int)));
+    TRYC(malloc0(&live_d, nf));
     TRYC(hipMemcpy(ids_d, ids.data(), nm * sizeof(int), hipMemcpyHostToDevice));
     TRYC(hipMemcpy(flen_d, flen.data(), nf * sizeof(int), hipMemcpyHostToDevice));
     TRYC(hipMemcpy(foff_d, foff.data(), (nf + 1) * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -4292,7 +4292,7 @@ int bslv_poly_dual_adjacency(bslv_poly *h)
         if ((rc = scan_totals(h, nbp, &tp))) { cleanup(); return rc; }
         if (tp.a > 0) {
             if (out_d) { (void)hipFree(out_d); out_d = nullptr; }
-            TRYC(hipMalloc(&out_d, (size_t)tp.a * sizeof(int2)));
+            TRYC(malloc0(&out_d, (size_t)tp.a * sizeof(int2)));
             hipLaunchKernelGGL(k_pair_emit, dim3(nbp), dim3(PB), 0, s, ids_d, nm, h->blks, h->pflag, h->bsum, out_d, 0);
             size_t base = h->dual_edges.size();
             h->dual_edges.resize(base + 2 * (size_t)tp.a);
