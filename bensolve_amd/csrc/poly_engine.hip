@@ -2765,9 +2765,11 @@ template <typename T>
 static int grow(T **p, size_t oldn, size_t newn, hipStream_t s, bool zero_tail = false)
 {
     T *q = nullptr;
-    HIP_TRY(malloc0(&q, newn * sizeof(T)));
-    if (*p && oldn) HIP_TRY(hipMemcpyAsync(q, *p, oldn * sizeof(T), hipMemcpyDeviceToDevice, s));
-    if (zero_tail) HIP_TRY(hipMemsetAsync(q + oldn, 0, (newn - oldn) * sizeof(T), s));
+    HIP_TRY(hipMalloc((void **)&q, newn * sizeof(T)));
+    const size_t keep = (*p && oldn) ? oldn : 0;
+    if (keep) HIP_TRY(hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, s));
+    (void)zero_tail;                                   // (what is not copied is ALWAYS zeroed: see malloc0 in common.h)
+    if (newn > keep) HIP_TRY(hipMemsetAsync(q + keep, 0, (newn - keep) * sizeof(T), s));
     HIP_TRY(hipStreamSynchronize(s));
     if (*p) (void)hipFree(*p);
     *p = q;
