@@ -28,7 +28,9 @@ template <class T>
 static inline hipError_t malloc0(T **p, size_t bytes)
 {
     hipError_t e = hipMalloc((void **)p, bytes);
+#ifndef BSLV_NO_MALLOC0            // (diagnostic builds only: the allocations as they were before this was found)
     if (e == hipSuccess && bytes) e = hipMemset((void *)*p, 0, bytes);
+#endif
     return e;
 }
 

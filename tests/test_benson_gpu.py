@@ -124,6 +124,36 @@ def test_cuts_handed_back_by_thin_rounds_are_applied_later():
     ph.assert_benson_results_agree(got, exp, tol=1e-6, allow_sliver=("S-small to termination with cuts handed back: different cut order at eps = POLY_EPS", 24))
 
 
+def test_an_engine_does_not_depend_on_who_used_the_memory_before():
+    """bench.py builds three engines in one process; the third once faulted on memory a destroyed engine had given back.
+    S-small to termination on fresh memory, then a larger engine is run for a few steps and destroyed, then S-small again: the
+    same LPs, cuts, pivots and the same polyhedron bit for bit."""
+    import hashlib
+
+    def run_small():
+        prob = synth.CONFIGS["S-small"]()
+        eng = BensonEngine(prob, eps=1e-7, pool_slots=4 * 2048 + 64)
+        assert eng.start() == 0
+        eng.run(2048)
+        tot = eng.totals()
+        d = eng.poly_dump()
+        eng.close()
+        h = hashlib.sha256()
+        for key in ("pu", "pi", "du", "di", "X", "Y", "E", "I"):
+            h.update(np.ascontiguousarray(d[key]).tobytes())
+        return tot, h.hexdigest()
+
+    first = run_small()
+    big = BensonEngine(synth.CONFIGS["S-mid"](), eps=1e-7, pool_slots=2 * 1024 + 64)
+    big.set_policy(1)
+    assert big.start() == 0
+    for _ in range(12):
+        big.step(1024)
+    big.close()
+    again = run_small()
+    assert first == again, (first, again)
+
+
 import os
 import json
 
