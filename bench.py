@@ -209,18 +209,22 @@ def main():
     #  * below, after the CPU baseline: the batch selection rule of rounds 1-2 (newest vertices first) on a fresh engine.
     long_window = None
     if world == 1 and pipe is None and args.workload == "S-mid" and not args.no_long_window:
-        extra = 4 * args.steps
-        l2 = c2 = f2 = 0
-        tl = time.perf_counter()
-        for _ in range(extra):
-            s = one_step()
-            l2 += s["lps"]; c2 += s["cuts"]; f2 += s.get("confirmed", 0)
-        sync()
-        dtl = time.perf_counter() - tl
-        print("bench: long window done (%d more steps, %.3f s)" % (extra, dtl), file=sys.stderr, flush=True)
-        long_window = {"steps": args.steps + extra, "lps_per_sec": round((lps + l2) / (dt + dtl), 1), "useful_lps_per_sec": round((cuts + confirmed + c2 + f2) / (dt + dtl), 1),
-                       "continuation_only": {"lps_per_sec": round(l2 / dtl, 1), "useful_lps_per_sec": round((c2 + f2) / dtl, 1)},
-                       "note": "the timed region plus 4x as many steps of the same run (not part of `value`)"}
+        try:
+            extra = 4 * args.steps
+            l2 = c2 = f2 = 0
+            tl = time.perf_counter()
+            for _ in range(extra):
+                s = one_step()
+                l2 += s["lps"]; c2 += s["cuts"]; f2 += s.get("confirmed", 0)
+            sync()
+            dtl = time.perf_counter() - tl
+            print("bench: long window done (%d more steps, %.3f s)" % (extra, dtl), file=sys.stderr, flush=True)
+            long_window = {"steps": args.steps + extra, "lps_per_sec": round((lps + l2) / (dt + dtl), 1), "useful_lps_per_sec": round((cuts + confirmed + c2 + f2) / (dt + dtl), 1),
+                           "continuation_only": {"lps_per_sec": round(l2 / dtl, 1), "useful_lps_per_sec": round((c2 + f2) / dtl, 1)},
+                           "note": "the timed region plus 4x as many steps of the same run (not part of `value`)"}
+        except Exception as e:      # (a figure beside the headline must not cost the headline)
+            long_window = {"error": str(e)}
+            print("bench: long window failed: %s" % e, file=sys.stderr, flush=True)
 
     c1 = snap["counts"]
     new_vertices = c1["new_vertices"] - nv0
@@ -332,41 +336,49 @@ def main():
         if args.workload == "S-mid" and not args.policy and not args.no_long_window:
             # the batch selection rule of rounds 1-2 on a fresh engine, same ramp / warm-up / steps: what BENCH_r01 / r02 measured
             print("bench: CPU baseline done; rounds-1-2 rule on a fresh engine ...", file=sys.stderr, flush=True)
-            e3 = BensonEngine(prob, eps=1e-7, pool_slots=pool_slots)
-            e3.set_policy(1)
-            e3.poly_call("debug_set", 11, 0); e3.poly_call("debug_set", 7, 512)      # (rounds by local minima, chunks of 512: round 2's cut phase)
-            e3.start()
-            for _ in range(200):
-                e3.step(B)
-                if e3.poly_call("unprocessed", 0)[3] >= B:
-                    break
-            for _ in range(args.warmup):
-                e3.step(B)
-            torch.cuda.synchronize(); t3 = time.perf_counter()
-            l3 = c3 = 0
-            for _ in range(args.steps):
-                s3 = e3.step(B)
-                l3 += s3["lps"]; c3 += s3["cuts"] + s3["confirmed"]
-            torch.cuda.synchronize(); t3 = time.perf_counter() - t3
-            e3.close()
-            print("bench: rounds-1-2 rule done", file=sys.stderr, flush=True)
-            cpu["policy_newest_first_rounds_of_local_minima"] = {"lps_per_sec": round(l3 / t3, 1), "useful_lps_per_sec": round(c3 / t3, 1), "lps_redundant_frac": round(1 - c3 / max(l3, 1), 4),
-                                                                  "note": "rounds 1-2's selection (newest vertices first) and cut phase (local minima of one order, chunks of 512) on a fresh engine over the same window; not part of `value`"}
+            try:
+                e3 = BensonEngine(prob, eps=1e-7, pool_slots=pool_slots)
+                e3.set_policy(1)
+                e3.poly_call("debug_set", 11, 0); e3.poly_call("debug_set", 7, 512)      # (rounds by local minima, chunks of 512: round 2's cut phase)
+                e3.start()
+                for _ in range(200):
+                    e3.step(B)
+                    if e3.poly_call("unprocessed", 0)[3] >= B:
+                        break
+                for _ in range(args.warmup):
+                    e3.step(B)
+                torch.cuda.synchronize(); t3 = time.perf_counter()
+                l3 = c3 = 0
+                for _ in range(args.steps):
+                    s3 = e3.step(B)
+                    l3 += s3["lps"]; c3 += s3["cuts"] + s3["confirmed"]
+                torch.cuda.synchronize(); t3 = time.perf_counter() - t3
+                e3.close()
+                print("bench: rounds-1-2 rule done", file=sys.stderr, flush=True)
+                cpu["policy_newest_first_rounds_of_local_minima"] = {"lps_per_sec": round(l3 / t3, 1), "useful_lps_per_sec": round(c3 / t3, 1), "lps_redundant_frac": round(1 - c3 / max(l3, 1), 4),
+                                                                      "note": "rounds 1-2's selection (newest vertices first) and cut phase (local minima of one order, chunks of 512) on a fresh engine over the same window; not part of `value`"}
+            except Exception as e:      # (a figure beside the headline must not cost the headline)
+                cpu["policy_newest_first_rounds_of_local_minima"] = {"error": str(e)}
+                print("bench: rounds-1-2 rule failed: %s" % e, file=sys.stderr, flush=True)
         if not args.no_pair and args.workload != "S-small":
             # like-for-like pair: S-small to termination on both sides (same problem, same eps, whole phase 2)
             sp = synth.CONFIGS["S-small"]()
             print("bench: S-small pair ...", file=sys.stderr, flush=True)
-            e2 = BensonEngine(sp, eps=1e-7, pool_slots=4 * 2048 + 64)
-            e2.start()
-            torch.cuda.synchronize(); tg = time.perf_counter()
-            e2.run(2048)
-            torch.cuda.synchronize(); tg = time.perf_counter() - tg
-            tot = e2.totals()
-            e2.close()
-            rc, fp, cs = oracle_api.benson_phase2_primal(sp, eps=1e-7)
-            fp.close()
-            cpu["whole_run_pair"] = {"workload": "S-small (q=3, n=100, m=200) phase 2 to termination", "gpu_secs": round(tg, 4), "gpu_lps": tot["lps"],
-                                     "cpu_secs": round(cs.secs_total, 4), "cpu_lps": cs.lps, "speedup_time_to_termination": round(cs.secs_total / max(tg, 1e-9), 2)}
+            try:
+                e2 = BensonEngine(sp, eps=1e-7, pool_slots=4 * 2048 + 64)
+                e2.start()
+                torch.cuda.synchronize(); tg = time.perf_counter()
+                e2.run(2048)
+                torch.cuda.synchronize(); tg = time.perf_counter() - tg
+                tot = e2.totals()
+                e2.close()
+                rc, fp, cs = oracle_api.benson_phase2_primal(sp, eps=1e-7)
+                fp.close()
+                cpu["whole_run_pair"] = {"workload": "S-small (q=3, n=100, m=200) phase 2 to termination", "gpu_secs": round(tg, 4), "gpu_lps": tot["lps"],
+                                         "cpu_secs": round(cs.secs_total, 4), "cpu_lps": cs.lps, "speedup_time_to_termination": round(cs.secs_total / max(tg, 1e-9), 2)}
+            except Exception as e:      # (a figure beside the headline must not cost the headline)
+                cpu["whole_run_pair"] = {"error": str(e)}
+                print("bench: S-small pair failed: %s" % e, file=sys.stderr, flush=True)
 
     if rank == 0:
         out = {
