@@ -22,17 +22,27 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // Device memory of the engines starts out as ZEROS.  A fresh process gets zero pages from the driver, a process that has destroyed
-// an engine gets that engine's memory back: without this the two differ (seen as a memory access fault in the third engine of a
-// bench run, never in a test process), and "reproducible bit for bit" would depend on who used the memory before.
+// an engine gets that engine's memory back: without this the two differ, and "reproducible bit for bit" would depend on who used
+// the memory before.  (Belt, not braces: the one read of an unwritten word that round 3 met as a memory access fault is fixed where
+// it happened -- DESIGN.md section 6 -- and tests/test_fill_gpu.py runs the engines on memory filled with OTHER bytes.)
+// Debugging aids: BSLV_FILL=<byte> (decimal or 0x..) fills fresh allocations and the uncopied tail of every grow() with that byte
+// instead of zero; BSLV_ALLOC_LOG=<file> appends "name pointer bytes file:line" per allocation (to match a fault address).
+int debug_fill();
+void debug_note_alloc(const char *name, const void *p, size_t bytes, const char *file, int line);
 template <class T>
-static inline hipError_t malloc0(T **p, size_t bytes)
+static inline hipError_t malloc0_impl(T **p, size_t bytes, hipStream_t s, bool on_stream, const char *name, const char *file, int line)
 {
     hipError_t e = hipMalloc((void **)p, bytes);
-#ifndef BSLV_NO_MALLOC0            // (diagnostic builds only: the allocations as they were before this was found)
-    if (e == hipSuccess && bytes) e = hipMemset((void *)*p, 0, bytes);
-#endif
+    if (e == hipSuccess && bytes) {
+        debug_note_alloc(name, (const void *)*p, bytes, file, line);
+        // (creation-time allocations: the null stream, which orders against every stream of the process; allocations made while an
+        // engine runs name their stream, so that the other engine stream of a pipelined driver is not held up)
+        e = on_stream ? hipMemsetAsync((void *)*p, debug_fill(), bytes, s) : hipMemset((void *)*p, debug_fill(), bytes);
+    }
     return e;
 }
+#define malloc0(p, bytes) bslv::malloc0_impl(p, bytes, nullptr, false, #p, __FILE__, __LINE__)
+#define malloc0s(p, bytes, stream) bslv::malloc0_impl(p, bytes, stream, true, #p, __FILE__, __LINE__)
 
 constexpr int WAVE = 64;
 

@@ -31,6 +31,23 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// debugging aids of common.h (malloc0 / grow): fill byte of fresh device memory, allocation log
+int debug_fill()
+{
+    static const int v = [] { const char *e = getenv("BSLV_FILL"); return e ? (int)(strtol(e, nullptr, 0) & 0xFF) : 0; }();
+    return v;
+}
+void debug_note_alloc(const char *name, const void *p, size_t bytes, const char *file, int line)
+{
+    static const char *path = getenv("BSLV_ALLOC_LOG");
+    if (!path) return;
+    FILE *f = fopen(path, "a");
+    if (!f) return;
+    const char *base = strrchr(file, '/');
+    fprintf(f, "%s %p %zu %s:%d\n", name, p, bytes, base ? base + 1 : file, line);
+    fclose(f);
+}
+
 constexpr int NS_L = 0, NS_U = 1, NS_F = 2, NS_S = 3;
 constexpr int ST_RUNNING = -1;
 constexpr int MODE_NONE = 0, MODE_PIVOT = 1, MODE_REFRESH = 2;
@@ -1235,13 +1252,13 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     L.objmode = cvals ? 1 : 0; L.cfirst = cfirst; L.ccnt = ccnt;
     if (cvals) {
         const size_t need = (size_t)B * ccnt;
-        if (need > h->cvals_cap) { if (h->cvals_d) (void)hipFree(h->cvals_d); h->cvals_d = nullptr; HIP_TRY(malloc0(&h->cvals_d, need * sizeof(double))); h->cvals_cap = need; }
+        if (need > h->cvals_cap) { if (h->cvals_d) (void)hipFree(h->cvals_d); h->cvals_d = nullptr; HIP_TRY(malloc0s(&h->cvals_d, need * sizeof(double), s)); h->cvals_cap = need; }
         HIP_TRY(hipMemcpyAsync(h->cvals_d, cvals, need * sizeof(double), hipMemcpyHostToDevice, s));
     }
     if (const char *e = getenv("BSLV_UPD_GRID")) h->upd_grid = std::max(64, atoi(e));
     {   // one work-list length per lock-step iteration, zeroed here: no reset between iterations
         const int need = L.maxit + 64;
-        if (need > h->nworkcap) { if (h->nwork_d) (void)hipFree(h->nwork_d); h->nwork_d = nullptr; HIP_TRY(malloc0(&h->nwork_d, need * sizeof(int))); h->nworkcap = need; }
+        if (need > h->nworkcap) { if (h->nwork_d) (void)hipFree(h->nwork_d); h->nwork_d = nullptr; HIP_TRY(malloc0s(&h->nwork_d, need * sizeof(int), s)); h->nworkcap = need; }
         HIP_TRY(hipMemsetAsync(h->nwork_d, 0, need * sizeof(int), s));
     }
     HIP_TRY(hipMemsetAsync(h->xstat_d, 0, 8 * sizeof(int), s));

@@ -1665,10 +1665,17 @@ __device__ __forceinline__ void flags_block(const PolyView &P, const int2 *E, in
     }
 }
 // nv_dev (rounds queued ahead of the host): the element count is still on the device, as ne_dev
+// halt (rounds, poly_rounds2_kernels.inc): RState::halt, halt2.  A round queued BEHIND one that did not go ahead (a capacity was
+// short, nothing was selected, ...) was given the edge buffer that round WOULD have written: every kernel of it must return at
+// once.  This one did not until round 4 -- it walked a buffer nobody had written with the old edge count and took its "edges" for
+// element numbers: P.cls[garbage].  Harmless on zero pages (edge (0, 0): nothing flagged, nothing marked), a memory access fault
+// on recycled memory that happened to hold large values (round 3; tests/test_fill_gpu.py).
 __global__ __launch_bounds__(1024) void k_flags2(PolyView P, const int2 *E, int ne_ub, const int *ne_dev, int nbe, int nv0, const int *counters,
-                                                 unsigned char *eflag, int *ecount, Tri *ebsum, Tri *vbsum, ZMarks Z, const int *nv_dev = nullptr)
+                                                 unsigned char *eflag, int *ecount, Tri *ebsum, Tri *vbsum, ZMarks Z, const int *nv_dev = nullptr,
+                                                 const int *halt = nullptr)
 {
     __shared__ Tri lds[16];
+    if (halt && (halt[0] != 0 || halt[1] != 0)) return;
     flags_block(P, E, ne_dev ? *ne_dev : ne_ub, nbe, (int)gridDim.x - nbe, nv_dev ? *nv_dev : nv0, counters, eflag, ecount, ebsum, vbsum, Z, (int)blockIdx.x, lds, false);
 }
 // emit pass.  Edge blocks: survivors -> Enew[0..nsurv), one new vertex per crossing edge (coordinates, flags,
@@ -2761,20 +2768,23 @@ static void v2h_map(const bslv_poly *h, const double *v, int is_dir, double *hp)
     }
 }
 
+// *p (oldn elements in use) becomes an array of newn elements; what is not copied is filled like a fresh allocation (zeros;
+// BSLV_FILL: see malloc0 in common.h).  zero_tail marks the arrays whose kernels RELY on the zeros (stamps, counters, keep marks).
 template <typename T>
-static int grow(T **p, size_t oldn, size_t newn, hipStream_t s, bool zero_tail = false)
+static int grow_impl(const char *name, int line, T **p, size_t oldn, size_t newn, hipStream_t s, bool zero_tail = false)
 {
     T *q = nullptr;
     HIP_TRY(hipMalloc((void **)&q, newn * sizeof(T)));
+    debug_note_alloc(name, (const void *)q, newn * sizeof(T), __FILE__, line);
     const size_t keep = (*p && oldn) ? oldn : 0;
     if (keep) HIP_TRY(hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, s));
-    (void)zero_tail;                                   // (what is not copied is ALWAYS zeroed: see malloc0 in common.h)
-    if (newn > keep) HIP_TRY(hipMemsetAsync(q + keep, 0, (newn - keep) * sizeof(T), s));
+    if (newn > keep) HIP_TRY(hipMemsetAsync(q + keep, zero_tail ? 0 : debug_fill(), (newn - keep) * sizeof(T), s));
     HIP_TRY(hipStreamSynchronize(s));
     if (*p) (void)hipFree(*p);
     *p = q;
     return 0;
 }
+#define grow(p, ...) grow_impl(#p, __LINE__, p, __VA_ARGS__)
 
 static int ensure_vcap(bslv_poly *h, int need)
 {
@@ -2935,7 +2945,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
         const bool tiled = nm >= h->fm_min && h->d > 1 && lds_tiled <= 48 * 1024;      // (more than 65535 row groups: several launches, below)
         const bool fm = tiled && h->member_lists && len_ub <= (1ll << 30);
         if (tiled) {
-            if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(malloc0(&h->nzlist, (nc + 1) * sizeof(int))); h->nzcap = nc; }
+            if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(malloc0s(&h->nzlist, (nc + 1) * sizeof(int), s)); h->nzcap = nc; }
             HIP_TRY(hipMemsetAsync(h->nzlist + h->nzcap, 0, sizeof(int), s));
         }
         if (fm) {
@@ -3730,7 +3740,7 @@ int bslv_poly_classify_batch_touch(bslv_poly *h, int B, const double *hps, unsig
     size_t need = (size_t)((B + 31) / 32) * h->P.cap;
     if (need > h->clswcap) { if ((rc = grow(&h->clsw, 0, need, h->stream))) return rc; h->clswcap = need; }
     int *tt = nullptr;
-    HIP_TRY(malloc0(&tt, (size_t)2 * std::max(nv, 1) * sizeof(int)));
+    HIP_TRY(malloc0s(&tt, (size_t)2 * std::max(nv, 1) * sizeof(int), h->stream));
     HIP_TRY(hipMemsetAsync(h->anyminus, 0, ((B + 31) / 32) * sizeof(unsigned), h->stream));
     launch_classify_batch(h->stream, h->P, h->hps_d, B, nv, h->clsw, h->anyminus, tt, tt + nv);
     HIP_TRY(hipGetLastError());
