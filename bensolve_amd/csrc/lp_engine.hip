@@ -294,8 +294,10 @@ __device__ __forceinline__ double hash01(int k)
 }
 // Workgroup: NT threads; NT_BIG for rows of 1536 columns and more (S-degenerate: 2011, ex09: 36 939) -- an LP's selection is a chain
 // of passes over N entries by ONE workgroup, and four times the threads shorten every pass.
+// ONE selection of LP b by the calling workgroup (every `return` below is taken by the whole workgroup).  Returns false when the LP
+// cannot select again before the next pass over its tableau (finished, waiting for a refresh, KP pivots pending).
 template <bool EXT>
-__global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const int *active, int nact, int cap2)
+__device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, const int cap2)
 {
     __shared__ double sv[NT_BIG / WAVE];
     __shared__ int si[NT_BIG / WAVE];
@@ -306,11 +308,9 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
     double *skey = reinterpret_cast<double *>(dyn_sel);          // [cap2] breakpoints |d_j| / |alpha_j| of the candidates
     int *sidx = reinterpret_cast<int *>(skey + cap2);             // [cap2] their columns
     unsigned char *sflag = reinterpret_cast<unsigned char *>(sidx + cap2);   // [N] 1 = column switches bound in this iteration
-    if ((int)blockIdx.x >= nact) return;
-    const int b = active[blockIdx.x];          // compacted list of the LPs still running
-    if (Bv.status[b] != ST_RUNNING || Bv.mode[b] == MODE_REFRESH) return;
+    if (Bv.status[b] != ST_RUNNING || Bv.mode[b] == MODE_REFRESH) return false;
     const int np = Bv.npend[b];
-    if (np >= KP) return;                      // waits for the pass over its tableau
+    if (np >= KP) return false;                // waits for the pass over its tableau
     const int tid = threadIdx.x;
     int slot = Bv.dst[b];
     // the stored tableau of this solve: the parent's slot until the first pass has written its own (see k_init)
@@ -372,11 +372,11 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
         if (ent.i < 0) {
             // dual feasible: the dual selection takes over again (it concludes, or repairs what rounding left infeasible)
             if (tid == 0) Bv.pflags[b] = pf & ~PF_PRIMAL;
-            return;
+            return true;
         }
         if (Bv.iters[b] >= L.maxit) {
             if (tid == 0) { Bv.status[b] = BSLV_LP_UNDEFINED; Bv.mode[b] = MODE_NONE; }
-            return;
+            return true;
         }
         q = ent.i;
         const int stq = nstat[q], kq = nh[q];
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
         tmax = block_min(tmax, sv);
         if (isinf(tmax)) {
             if (tid == 0) { Bv.status[b] = BSLV_LP_UNBOUNDED; Bv.mode[b] = MODE_NONE; }
-            return;
+            return true;
         }
         ValIdx lv{0.0, -1};
         for (int i = tid; i < M; i += NT) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
                 Bv.iters[b] += 1;
                 atomicAdd(&Bv.xstat[2], 1);
             }
-            return;
+            return true;
         }
         r = lv.i >> 1;
         below = !(lv.i & 1);                   // the leaving variable goes to its lower bound
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
             if (tid == 0 && (wrong1 || wrongb)) atomicAdd(&Bv.xstat[3], 1);
             if (wrong1) {
                 if (tid == 0) { Bv.pflags[b] = pf | PF_PRIMAL; if (L.trace == b) printf("lp %d it %d perturbation off -> primal clean-up\n", b, Bv.iters[b]); }
-                return;
+                return true;
             }
             if (tid == 0) Bv.pflags[b] = pf;
             if (wrongb) {
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
                     else if (st == NS_U && v > TOL_DJ) { nstat[j] = NS_L; xN[j] = LO(L, Bv, b, k); }
                 }
                 if (tid == 0) { Bv.mode[b] = MODE_REFRESH; Bv.verified[b] &= 2; if (L.trace == b) printf("lp %d it %d perturbation off -> bound switches\n", b, Bv.iters[b]); }
-                return;
+                return true;
             }
             dwork = drow;
         }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
         // (Not when the solve started on an artificial bound: values of 1e7 leave rounding debris of 1e-9 in beta.)
         if (!(Bv.verified[b] & 1) && (Bv.iters[b] > REFRESH_AFTER || (Bv.verified[b] & 2))) {
             if (tid == 0) Bv.mode[b] = MODE_REFRESH;          // k_flush applies what is pending and recomputes beta
-            return;
+            return true;
         }
         // optimal for the bounded problem; unbounded if an artificial bound is active
         double flag = 0.0;
@@ -500,11 +500,11 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
         }
         flag = block_max(flag, sv);
         if (tid == 0) { Bv.status[b] = flag > 0.0 ? BSLV_LP_UNBOUNDED : BSLV_LP_OPTIMAL; Bv.mode[b] = MODE_NONE; }
-        return;
+        return true;
     }
     if (Bv.iters[b] >= L.maxit) {
         if (tid == 0) { Bv.status[b] = BSLV_LP_UNDEFINED; Bv.mode[b] = MODE_NONE; }
-        return;
+        return true;
     }
     r = best.i >> 1;
     below = best.i & 1;
@@ -593,10 +593,10 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
     if (isinf(th)) {                      // no entering candidate: primal infeasible ...
         if (!(Bv.verified[b] & 1)) {      // ... unless the violation is rounding debris in beta: recompute it first
             if (tid == 0) Bv.mode[b] = MODE_REFRESH;
-            return;
+            return true;
         }
         if (tid == 0) { Bv.status[b] = BSLV_LP_INFEASIBLE; Bv.mode[b] = MODE_NONE; }
-        return;
+        return true;
     }
     // pass 2: largest |pivot| within the bound
     ValIdx piv{0.0, -1};
@@ -702,7 +702,23 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
         }
     }
     if (tid == 0) Bv.npend[b] = np + 1;
+    return true;
 }
+// One launch selects up to nsel pivots per LP, one after the other, by the same workgroup: the KP selections between two passes
+// over the tableau depend only on the LP's own vectors (beta, the reduced-cost row, the pending pivot rows and multipliers) -- no
+// grid-wide dependency asks for a launch each (rounds 1-3 launched this kernel KP times per pass, 17 % of all GPU time in
+// launches of 25 us; BSLV_SELECT_FUSE=0 brings that form back: the results are the same bit for bit, tests/test_lp_gpu.py).
+template <bool EXT>
+__global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const int *active, int nact, int cap2, int nsel)
+{
+    if ((int)blockIdx.x >= nact) return;
+    const int b = active[blockIdx.x];          // compacted list of the LPs still running
+    for (int sdx = 0; sdx < nsel; sdx++) {
+        if (sdx) __syncthreads();              // (what thread 0 / every thread wrote for the LP -- status, mode, pending count, beta, reduced costs -- is read by all)
+        if (!select_once<EXT>(L, Bv, b, cap2)) break;
+    }
+}
+
 
 // ---- which LPs need a pass over their tableau: pending pivots to apply, or beta to recompute ----
 __global__ void k_list_pending(BatchView Bv, const int *active, int nact, int it)
@@ -1298,6 +1314,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     // (measured, BSLV_SELECT_NT: S-degenerate, 2011 columns, 64 LPs per step: LP phase 67.6 / 52.0 / 46.6 ms with 256 / 512 / 1024 threads;
     //  S-degenerate-q4 to termination with 256 LPs per step 12.1 -> 10.4 s; same pivots)
     const int sel_nt = getenv("BSLV_SELECT_NT") ? atoi(getenv("BSLV_SELECT_NT")) : (L.N >= 1536 ? NT_BIG : NT);
+    const int sel_per_launch = (getenv("BSLV_SELECT_FUSE") && atoi(getenv("BSLV_SELECT_FUSE")) == 0) ? 1 : KP;     // selections per k_select launch
     int it = 0, chunk = 1, running = B;
     for (int b = 0; b < B; b++) h->active_h[b] = b;
     HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, B * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1305,9 +1322,9 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     h->last_update_ms = 0;
     while (running > 0 && it < L.maxit + 8) {
         for (int c = 0; c < chunk; c++, it++) {
-            for (int lev = 0; lev < KP; lev++) {
-                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(sel_nt), sel_lds, s, L, bv, h->active_d, running, cap2);
-                else hipLaunchKernelGGL(k_select<false>, dim3(running), dim3(sel_nt), 0, s, L, bv, h->active_d, running, 0);
+            for (int lev = 0; lev < KP; lev += sel_per_launch) {
+                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(sel_nt), sel_lds, s, L, bv, h->active_d, running, cap2, sel_per_launch);
+                else hipLaunchKernelGGL(k_select<false>, dim3(running), dim3(sel_nt), 0, s, L, bv, h->active_d, running, 0, sel_per_launch);
             }
             hipLaunchKernelGGL(k_list_pending, dim3((running + 255) / 256), dim3(256), 0, s, bv, h->active_d, running, it);
             if (h->profile) {

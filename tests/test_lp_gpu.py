@@ -459,3 +459,43 @@ def test_presolve_keeps_the_model_of_the_caller_primal_and_dual():
                     assert (dual[k] > 0 and at_lo) or (dual[k] < 0 and at_up) or (at_lo and at_up), (trial, mode, k, dual[k], prim[k], lo[k], up[k])
             out[mode] = z
         assert abs(out["presolve"] - out["plain"]) < 1e-9 * (1 + abs(out["plain"]))
+
+
+@pytest.mark.parametrize("kind", ["covering", "boxed"])
+def test_one_selection_launch_per_pass_is_bit_identical_to_six(monkeypatch, kind):
+    """k_select loops over the KP = 6 selections between two passes over the tableau inside ONE launch (round 4); BSLV_SELECT_FUSE=0
+    launches it once per selection as rounds 1-3 did.  Same pivots, same objective values, primal values and duals bit for bit
+    (plain dual simplex on covering LPs; the extended selection -- long steps, perturbation, primal clean-up -- on boxed ones)."""
+    import oracle_api  # noqa: F401  (same import order as the other tests)
+    rng = np.random.default_rng(12)
+    if kind == "covering":
+        prob = synth.covering_vlp(200, 100, 3, 1)
+        B = 96
+        model = P2Model(prob)
+        V = _random_V(model, prob, rng, B)
+    else:
+        prob = synth.fold_singleton_rows(synth.degenerate_vlp(240, 120, 4, 5))
+        B = 48
+        model = P2Model(prob)
+        V = rng.random((B, 120)) @ prob["P"].T + rng.normal(scale=0.5, size=(B, 4))
+        V[: B // 4] = np.round(V[: B // 4])
+    ub = model.ub_for(V)
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("BSLV_SELECT_FUSE", fuse)
+        eng = LpEngine.from_model(model, pool_slots=B + 1)
+        eng.reset_slot(0)
+        st0, it0 = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+        assert st0[0] == 4
+        src = np.zeros(B, np.int32)
+        dst = np.arange(1, B + 1, dtype=np.int32)
+        st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+        assert np.all(st == 4)
+        res[fuse] = (int(it0[0]), it.copy(), eng.obj(dst).copy(), eng.dual(dst, model.w_first, model.q).copy(), eng.primal(dst, model.y_first, model.q).copy(),
+                     eng.primal(dst, model.M, prob["n"]).copy())
+        eng.close()
+    a, b = res["0"], res["1"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]), "pivot counts differ"
+    assert a[1].sum() > B, "the batch needs pivots for this to mean anything"
+    for x, y in zip(a[2:], b[2:]):
+        assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
