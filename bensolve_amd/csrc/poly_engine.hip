@@ -45,6 +45,11 @@ struct PolyView {
     int *inc_len;           // cap
     int *pool;              // poolcap
     unsigned char *keep;    // poolcap (all zero between cuts)
+    // Long lists (extreme directions: tens of thousands of facets on covering problems) are rebuilt WITH SLACK, and while the slack lasts
+    // an on-plane element's list is compacted and extended where it lies instead of being copied to the end of the pool -- the copy of
+    // a 50 000-entry list by one wave was 150 us of every round.  capx[i] = (offset of the list the room belongs to) << 32 | room;
+    // valid only while inc_off[i] still is that offset (zero: none).
+    unsigned long long *capx;   // cap
     // hot mode (a chunk of cuts whose batched classification is known): the per-cut element passes only visit the
     // elements some cut of the chunk does not leave strictly inside (hv, ascending ids) and those created since
     // the chunk began (ids >= nv_base); everything else is PLUS for every cut of the chunk.  hv == nullptr: all.
@@ -57,6 +62,20 @@ struct PolyView {
     unsigned *lbits;
     int lstride;
 };
+// pool entries the rebuilt list of on-plane element i needs when k facets are appended: 0 = it stays where it is (zero_room_inplace)
+__device__ __forceinline__ bool zero_room_inplace(const PolyView &P, int i, int n, int k)
+{
+    if (n <= 64) return false;                                  // (LONGN: only lists that take the wave-cooperative path)
+    const unsigned long long x = P.capx[i];
+    return (unsigned)(x >> 32) == P.inc_off[i] && (long long)(x & 0xFFFFFFFFull) >= (long long)n + k;
+}
+__device__ __forceinline__ int zero_room(const PolyView &P, int i, int k)
+{
+    const int n = P.inc_len[i];
+    if (n <= 64) return n + k;
+    if (zero_room_inplace(P, i, n, k)) return 0;
+    return n + k + (n >> 2 > 64 ? n >> 2 : 64);
+}
 __device__ __host__ inline int vm_count(const PolyView &P, int nv) { return P.hv ? P.nhv + (nv - P.nv_base) : nv; }
 __device__ __forceinline__ int vm_id(const PolyView &P, int idx) { return P.hv ? (idx < P.nhv ? P.hv[idx] : P.nv_base + (idx - P.nhv)) : idx; }
 
@@ -222,8 +241,8 @@ __device__ __forceinline__ void classify_body(const PolyView &P, const Hp &hp, i
         signed char c = 2;
         if (fl & F_USED) { c = classify_one(P, hp, i, fl); isminus = c < 0; iszero = c == 0; }
         if (iszero) {
-            zlen = P.inc_len[i] + 1;               // upper bound of its rebuilt incidence list
-            if (zlen - 1 > LONGN) { const int k = atomicAdd(&counters[3], 1); if (k < ZMAX) zlist[k] = i; }
+            zlen = zero_room(P, i, 1);             // room of its rebuilt incidence list (0: a long list with slack is rebuilt where it lies)
+            if (P.inc_len[i] > LONGN) { const int k = atomicAdd(&counters[3], 1); if (k < ZMAX) zlist[k] = i; }
         }
         P.cls[i] = c;
     }
@@ -262,6 +281,47 @@ __device__ __forceinline__ unsigned long long spread32(unsigned x)
     v = (v | (v << 2)) & 0x3333333333333333ull;
     v = (v | (v << 1)) & 0x5555555555555555ull;
     return v;
+}
+__device__ __forceinline__ unsigned compress32(unsigned long long v)      // inverse of spread32: the even bits of v
+{
+    v &= 0x5555555555555555ull;
+    v = (v | (v >> 1)) & 0x3333333333333333ull;
+    v = (v | (v >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v >> 4)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v >> 8)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v >> 16)) & 0x00000000FFFFFFFFull;
+    return (unsigned)v;
+}
+__device__ __forceinline__ unsigned r2_touch32(unsigned long long raw) { return compress32(raw ^ (raw >> 1)); }      // classes 01 MINUS, 10 ZERO
+__device__ __forceinline__ unsigned r2_minus32(unsigned long long raw) { return compress32(raw & ~(raw >> 1)); }     // class 01
+// ---- owners of on-plane elements in a round of independent cuts (poly_rounds2_kernels.inc, "Elements shared by the cuts of a round") ----
+// What the flags / emit passes and the prunes need to know about the round: the element-major class words of the chunk (hw, wm:
+// which words hold a touch), the selected cuts as a bit mask (selw) and their number in the selection (selmap), the owner code of
+// every element (cutof: s >= 0 one cut, -1 - k: ZERO for k >= 2 selected cuts).  cutof == nullptr: the one-cut pipeline.
+struct R2Own { const int *cutof; const unsigned long long *hw; const unsigned *wm; const unsigned *selw; const int *selmap; int nw; };
+// owners of element i among the selected cuts, ascending: f(o) for every owner o (index in the chunk)
+template <class F>
+__device__ __forceinline__ void r2_for_owners(const unsigned long long *__restrict__ hw, const unsigned *__restrict__ wm, int nw, const unsigned *selw, int i, F f)
+{
+    unsigned m = wm[i];
+    while (m) {
+        const int w = __ffs((int)m) - 1;
+        m &= m - 1;
+        if (!selw[w]) continue;
+        unsigned t = r2_touch32(hw[(size_t)i * nw + w]) & selw[w];
+        while (t) { const int bit = __ffs((int)t) - 1; t &= t - 1; f(w * 32 + bit); }
+    }
+}
+// do two ZERO elements have a selected cut in common?
+__device__ __forceinline__ bool r2_common_owner(const unsigned long long *__restrict__ hw, const unsigned *__restrict__ wm, int nw, const unsigned *selw, int x, int y)
+{
+    unsigned m = wm[x] & wm[y];
+    while (m) {
+        const int w = __ffs((int)m) - 1;
+        m &= m - 1;
+        if (selw[w] && (r2_touch32(hw[(size_t)x * nw + w]) & r2_touch32(hw[(size_t)y * nw + w]) & selw[w])) return true;
+    }
+    return false;
 }
 // acc = 2 acc + (s > t), t wave-uniform: the compare leaves its mask in VCC and ONE add-with-carry shifts the bit in (the compiler
 // builds the word from v_cndmask + v_or3 + shifts: two vector instructions per bit instead of one)
@@ -715,6 +775,32 @@ __device__ __forceinline__ const unsigned *lrow(const PolyView &P, int v)
     const int sl = P.lslot[v];
     return sl >= 0 ? P.lbits + (size_t)sl * P.lstride : nullptr;
 }
+// An element that got a membership bitmap at the start of the chunk (its list was long then) and whose list has since become
+// short is rebuilt by ONE thread (the short path of the emit passes): its bitmap must follow, an edge may still consult it.
+__device__ __forceinline__ void relist_bitmap(const PolyView &P, int v, unsigned off, int n)
+{
+    unsigned *lb = const_cast<unsigned *>(lrow(P, v));
+    if (!lb) return;
+    for (int w = 0; w < P.lstride; w++) lb[w] = 0u;
+    for (int j = 0; j < n; j++) { const int g = P.pool[off + j]; lb[g >> 5] |= 1u << (g & 31); }
+}
+// Intersection of two sorted lists of very different lengths: every entry of the short one is looked up in the long one by binary
+// search -- ns log2(nl) loads instead of the ns + nl of the merge (a point on 20..60 facets against an extreme direction on thousands,
+// when the direction has no membership bitmap: the merge was hundreds of microseconds of dependent loads per edge on covering problems).
+// f(value, position in a, position in b) for every common entry, in ascending order.
+template <class F>
+__device__ __forceinline__ void isect_each(const int *a, int na, const int *b, int nb, F f)
+{
+    if ((long long)na * 12 < nb) { for (int i = 0; i < na; i++) { const int x = a[i]; const int p = find_sorted(b, nb, x); if (p >= 0) f(x, i, p); } return; }
+    if ((long long)nb * 12 < na) { for (int j = 0; j < nb; j++) { const int y = b[j]; const int p = find_sorted(a, na, y); if (p >= 0) f(y, p, j); } return; }
+    int i = 0, j = 0;
+    while (i < na && j < nb) {
+        const int x = a[i], y = b[j];
+        if (x == y) f(x, i, j);
+        i += (x <= y);
+        j += (y <= x);
+    }
+}
 __device__ __forceinline__ int isect_count_fast(const int *a, int na, const int *b, int nb)
 {
     if (na <= LCAP && nb <= LCAP) {
@@ -728,7 +814,9 @@ __device__ __forceinline__ int isect_count_fast(const int *a, int na, const int 
         load_list(ashort ? a : b, ashort ? na : nb, S);
         return __popc(match_mask_long(S, ashort ? na : nb, ashort ? b : a, ashort ? nb : na, pos));
     }
-    return isect_count(a, na, b, nb);
+    int n = 0;
+    isect_each(a, na, b, nb, [&](int, int, int) { n++; });
+    return n;
 }
 
 // ---------------- E: edges ----------------
@@ -1418,13 +1506,9 @@ __device__ __forceinline__ void set_keep(unsigned char *K, int idx)
 {
     if (!__hip_atomic_load(&K[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) K[idx] = 1;
 }
-__device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed, const ZMarks &Z, const int *counters)
+// (z: the on-plane element, pl: the other end, PLUS for z's cut)
+__device__ __forceinline__ void mark_keep_za(const PolyView &P, const int z, const int pl, const ZMarks &Z, const int *counters)
 {
-    const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
-    int z = -1, pl = -1;
-    if (ca == 0 && cb == 1) { z = ed.x; pl = ed.y; }
-    else if (ca == 1 && cb == 0) { z = ed.y; pl = ed.x; }
-    if (z < 0) return;
     const int *A = P.pool + P.inc_off[z], *Bp = P.pool + P.inc_off[pl];
     unsigned char *K = P.keep + P.inc_off[z];
     const int na = P.inc_len[z], nb = P.inc_len[pl];
@@ -1458,15 +1542,7 @@ __device__ __forceinline__ void mark_keep(const PolyView &P, const int2 ed, cons
         unsigned m = match_mask_long(RB, nb, A, na, pos);
 #pragma unroll
         for (int b2 = 0; b2 < LCAP; b2++) if ((m >> b2) & 1u) set_keep(K, pos[b2]);
-    } else {
-        int i = 0, j = 0;
-        while (i < na && j < nb) {
-            int x = A[i], y = Bp[j];
-            if (x == y) set_keep(K, i);
-            i += (x <= y);
-            j += (y <= x);
-        }
-    }
+    } else isect_each(A, na, Bp, nb, [&](int, int i, int) { set_keep(K, i); });
 }
 
 // What the host decides after round A, decided on the device as well, so that round B can be queued before the
@@ -1553,22 +1629,14 @@ __device__ __forceinline__ ZLocal zlocal_load(const ZMarks &Z, const int *counte
 // marks / ZMarks stamps of a ZERO-PLUS edge (only once the cut is known to remove something: counters[0] = #MINUS).
 // Returns (survives, crosses, list length of the new vertex).  Classes are read through P.cls.
 struct LongStamp { const int *list; int n; int *zrow; };       // facets of a long PLUS end still to be stamped in a ZMarks row (by the whole wave)
-__device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e, const int *counters, const ZLocal &zl, unsigned char *eflag, int *ecount,
-                                         const ZMarks &Z, LongStamp &ls)
+// One job of an edge in the flags pass: the intersection of the incidence lists of its ends -- a crossing edge needs its size (the
+// list of the new vertex), an edge from an on-plane element ia to an element ib that is PLUS for ia's cut needs the positions in
+// ia's list (its keep marks / ZMarks stamps): one shared code path, so that a wave holding edges of both kinds does not walk two
+// chains one after the other.  Returns the list length of the new vertex (cross) or 0.
+__device__ __forceinline__ int edge_job(const PolyView &P, const int2 ed, int ia, int ib, bool cross, const int *counters, const ZLocal &zl, const ZMarks &Z, LongStamp &ls)
 {
-    ls.n = 0;
-    Tri t{0, 0, 0};
-    const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
-    unsigned char f = 0;
-    if ((ca == -1 && cb == 1) || (ca == 1 && cb == -1)) { f = (ca == -1) ? 2 : 3; t.b = 1; }
-    else if (ca >= 0 && cb >= 0 && !(ca == 0 && cb == 0)) { f = (ca == 0 || cb == 0) ? 4 : 1; t.a = 1; }
-    eflag[e] = f;
-    const bool cross = f == 2 || f == 3, mark = f == 4 && counters[0] > 0;
-    if (!(cross || mark)) return t;
-    // both need the intersection of the two incidence lists -- a crossing edge its size (the list of the new
-    // vertex), a ZERO-PLUS edge the positions in the ZERO element's list (its keep marks): one shared
-    // code path, so that a wave holding edges of both kinds does not walk two chains one after the other
-    const int ia = (mark && ca != 0) ? ed.y : ed.x, ib = ia == ed.x ? ed.y : ed.x;      // A = the ZERO element of a marking edge
+    const bool mark = !cross;
+    int tc = 0;
     const int na = P.inc_len[ia], nb = P.inc_len[ib];
     int zid = -1;
     if (mark && na > LONGN) {
@@ -1594,7 +1662,7 @@ __device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e
         int RA[LCAP], RB[LCAP];
         load_list(P.pool + P.inc_off[ia], na, RA); load_list(P.pool + P.inc_off[ib], nb, RB);
         unsigned m = match_mask(RA, na, RB);
-        if (cross) t.c = __popc(m) + 1;
+        if (cross) tc = __popc(m) + 1;
         else {
             unsigned char *K = P.keep + P.inc_off[ia];
             while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // short list: plain stores, nothing to wait for
@@ -1617,11 +1685,53 @@ __device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e
                     while (m) { const int a = __ffs((int)m) - 1; m &= m - 1; K[a] = 1; }      // plain stores, nothing to wait for
                 }
             }
-            if (cross) t.c = cnt + 1;
-        } else if (cross) t.c = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
-        else mark_keep(P, ed, Z, counters);
+            if (cross) tc = cnt + 1;
+        } else if (cross) tc = isect_count_fast(P.pool + P.inc_off[ia], na, P.pool + P.inc_off[ib], nb) + 1;
+        else mark_keep_za(P, ia, ib, Z, counters);
     }
-    if (cross) ecount[e] = t.c;
+    return tc;
+}
+// One edge of the flags pass: its flag (eflag), the list length of the new vertex of a crossing edge (ecount), the keep
+// marks / ZMarks stamps of an edge from an on-plane element to an element that is PLUS for its cut (only once the cut is known to
+// remove something: counters[0] = #MINUS).  Returns (survives, crosses, list length of the new vertex).  Classes are read through
+// P.cls; own (rounds of independent cuts): which cut(s) an on-plane element belongs to.
+//   eflag: 0 dropped, 1 survives, 2 / 3 crossing (x / y MINUS), 4 survives with one end on a plane, 5 survives with both ends on
+//   planes of DIFFERENT cuts (rounds only)
+__device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e, const int *counters, const ZLocal &zl, unsigned char *eflag, int *ecount,
+                                         const ZMarks &Z, LongStamp (&ls)[2], const R2Own &own)
+{
+    ls[0].n = 0; ls[1].n = 0;
+    Tri t{0, 0, 0};
+    const signed char ca = P.cls[ed.x], cb = P.cls[ed.y];
+    unsigned char f = 0;
+    bool mark_x = false, mark_y = false;       // x (y) is on the plane of ONE cut for which the other end is PLUS: it keeps the facets the two share
+    if ((ca == -1 && cb == 1) || (ca == 1 && cb == -1)) { f = (ca == -1) ? 2 : 3; t.b = 1; }
+    else if (ca >= 0 && cb >= 0) {
+        if (ca == 0 && cb == 0) {
+            if (own.cutof) {
+                const int cx = own.cutof[ed.x], cy = own.cutof[ed.y];
+                const bool common = (cx >= 0 && cy >= 0) ? cx == cy : r2_common_owner(own.hw, own.wm, own.nw, own.selw, ed.x, ed.y);
+                if (!common) { f = 5; t.a = 1; mark_x = cx >= 0; mark_y = cy >= 0; }
+            }
+        } else if (ca == 0 || cb == 0) {
+            f = 4; t.a = 1;
+            const int z = ca == 0 ? ed.x : ed.y;
+            const bool single = !own.cutof || own.cutof[z] >= 0;       // (an element shared by several cuts of a round keeps its whole list: no marks)
+            mark_x = single && ca == 0; mark_y = single && cb == 0;
+        } else { f = 1; t.a = 1; }
+    }
+    eflag[e] = f;
+    const bool cross = f == 2 || f == 3;
+    if (!cross && counters[0] <= 0) return t;
+    // at most two jobs (both only for f == 5), ONE copy of the job's code: job 0 = the crossing edge, or x marked by y; job 1 = y marked by x
+    const int first = (cross || mark_x) ? 0 : 1, last = (!cross && mark_y) ? 1 : 0;
+#pragma unroll 1
+    for (int job = first; job <= last; job++) {
+        LongStamp l{nullptr, 0, nullptr};
+        const int tc = edge_job(P, ed, job ? ed.y : ed.x, job ? ed.x : ed.y, cross, counters, zl, Z, l);
+        if (job) ls[1] = l; else ls[0] = l;
+        if (cross) { t.c = tc; ecount[e] = tc; }
+    }
     return t;
 }
 // Virtual workgroup vb of the (nbe + nbv) workgroups of a flags pass, executed by the calling workgroup (blockDim.x edges or
@@ -1629,7 +1739,7 @@ __device__ __forceinline__ Tri flag_edge(const PolyView &P, const int2 ed, int e
 // the long dependent chains -- sit at the end of the arrays and must not wait for a second wave of workgroups.
 // accumulate: the edge sums are ADDED to ebsum (zeroed beforehand): another workgroup may own part of the same block.
 __device__ __forceinline__ void flags_block(const PolyView &P, const int2 *E, int ne, int nbe, int nbv, int nv0, const int *counters, unsigned char *eflag,
-                                            int *ecount, Tri *ebsum, Tri *vbsum, const ZMarks &Z, int vb, Tri *lds, bool accumulate)
+                                            int *ecount, Tri *ebsum, Tri *vbsum, const ZMarks &Z, int vb, Tri *lds, bool accumulate, const R2Own &own)
 {
     const int BS = blockDim.x;
     Tri t{0, 0, 0};
@@ -1638,18 +1748,21 @@ __device__ __forceinline__ void flags_block(const PolyView &P, const int2 *E, in
         const int eb = nbe - 1 - vb;
         const ZLocal zl = zlocal_load(Z, counters);
         const int e = eb * BS + threadIdx.x;
-        LongStamp ls{nullptr, 0, nullptr};
-        if (e < ne) t = flag_edge(P, E[e], e, counters, zl, eflag, ecount, Z, ls);
+        LongStamp ls[2] = {{nullptr, 0, nullptr}, {nullptr, 0, nullptr}};
+        if (e < ne) t = flag_edge(P, E[e], e, counters, zl, eflag, ecount, Z, ls, own);
         {   // long lists to stamp: all lanes of the wave share each one
             const int lane = threadIdx.x & 63;
-            unsigned long long todo = __ballot(ls.n > 0);
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int *L = (const int *)__shfl((unsigned long long)(uintptr_t)ls.list, src, WAVE);
-                int *zr = (int *)__shfl((unsigned long long)(uintptr_t)ls.zrow, src, WAVE);
-                const int n = __shfl(ls.n, src, WAVE);
-                for (int j = lane; j < n; j += WAVE) zr[L[j]] = Z.stamp;
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                unsigned long long todo = __ballot(ls[side].n > 0);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int *L = (const int *)__shfl((unsigned long long)(uintptr_t)ls[side].list, src, WAVE);
+                    int *zr = (int *)__shfl((unsigned long long)(uintptr_t)ls[side].zrow, src, WAVE);
+                    const int n = __shfl(ls[side].n, src, WAVE);
+                    for (int j = lane; j < n; j += WAVE) zr[L[j]] = Z.stamp;
+                }
             }
         }
         (void)block_exscan(t, &tot, lds);
@@ -1659,7 +1772,11 @@ __device__ __forceinline__ void flags_block(const PolyView &P, const int2 *E, in
         }
     } else {
         const int b = nbe + nbv - 1 - vb, idx = b * BS + threadIdx.x;
-        if (idx < vm_count(P, nv0)) { const int i = vm_id(P, idx); if (P.cls[i] == 0) { t.a = 1; t.c = P.inc_len[i] + 1; } }
+        if (idx < vm_count(P, nv0)) {
+            const int i = vm_id(P, idx);
+            // (the rebuilt list of an on-plane element: its old entries + one facet per cut it belongs to)
+            if (P.cls[i] == 0) { t.a = 1; const int co = own.cutof ? own.cutof[i] : 0; t.c = zero_room(P, i, co < -1 ? -1 - co : 1); }
+        }
         (void)block_exscan(t, &tot, lds);
         if (threadIdx.x == 0) vbsum[b] = tot;
     }
@@ -1672,11 +1789,17 @@ __device__ __forceinline__ void flags_block(const PolyView &P, const int2 *E, in
 // on recycled memory that happened to hold large values (round 3; tests/test_fill_gpu.py).
 __global__ __launch_bounds__(1024) void k_flags2(PolyView P, const int2 *E, int ne_ub, const int *ne_dev, int nbe, int nv0, const int *counters,
                                                  unsigned char *eflag, int *ecount, Tri *ebsum, Tri *vbsum, ZMarks Z, const int *nv_dev = nullptr,
-                                                 const int *halt = nullptr)
+                                                 const int *halt = nullptr, R2Own own = R2Own{nullptr, nullptr, nullptr, nullptr, nullptr, 0})
 {
     __shared__ Tri lds[16];
+    __shared__ unsigned s_selw[32];
     if (halt && (halt[0] != 0 || halt[1] != 0)) return;
-    flags_block(P, E, ne_dev ? *ne_dev : ne_ub, nbe, (int)gridDim.x - nbe, nv_dev ? *nv_dev : nv0, counters, eflag, ecount, ebsum, vbsum, Z, (int)blockIdx.x, lds, false);
+    if (own.cutof) {       // (the selection of the round as a bit mask: read by every edge whose ends are both on a plane)
+        if (threadIdx.x < 32) s_selw[threadIdx.x] = (int)threadIdx.x < own.nw ? own.selw[threadIdx.x] : 0u;
+        __syncthreads();
+        own.selw = s_selw;
+    }
+    flags_block(P, E, ne_dev ? *ne_dev : ne_ub, nbe, (int)gridDim.x - nbe, nv_dev ? *nv_dev : nv0, counters, eflag, ecount, ebsum, vbsum, Z, (int)blockIdx.x, lds, false, own);
 }
 // emit pass.  Edge blocks: survivors -> Enew[0..nsurv), one new vertex per crossing edge (coordinates, flags,
 // incidence list, its edge to the PLUS end at Enew[nsurv + crossidx]).  Vertex blocks: MINUS elements leave,
@@ -1794,15 +1917,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
 #pragma unroll
                         for (int a = 0; a < LCAP; a++) if ((m >> a) & 1u) out[n++] = RS[a];
                     }
-                } else {
-                    int i = 0, j = 0;
-                    while (i < na && j < nb) {
-                        int x = A[i], y = Bp[j];
-                        if (x == y) out[n++] = x;
-                        i += (x <= y);
-                        j += (y <= x);
-                    }
-                }
+                } else isect_each(A, na, Bp, nb, [&](int x, int, int) { out[n++] = x; });
             }
             out[n++] = facet;
             P.inc_off[w] = off;
@@ -1821,11 +1936,12 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
     unsigned off_old = 0;
     if (valid) {
         c = P.cls[i];
-        if (c == 0) { off_old = P.inc_off[i]; n = P.inc_len[i]; t.a = 1; t.c = n + 1; }
+        if (c == 0) { off_old = P.inc_off[i]; n = P.inc_len[i]; t.a = 1; t.c = zero_room(P, i, 1); }
     }
+    const int room = t.c;                      // (0: a long list with slack, rebuilt where it lies)
     Tri ex = block_exscan(t, &tot, lds);
     ex = tri_add(ex, own_scan ? pre_v : vbpre[b]);
-    const unsigned off_new = pool_z + (unsigned)ex.c;
+    const unsigned off_new = (c == 0 && room == 0) ? off_old : pool_z + (unsigned)ex.c;
     const bool longz = (c == 0) && n > LONGN;
     {   // long lists (extreme directions): ordered compaction by the whole wave (ballot ranks), then the new facet
         unsigned long long todo = __ballot(longz);
@@ -1833,7 +1949,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const unsigned oo = __shfl(off_old, src, WAVE), on = __shfl(off_new, src, WAVE);
-            const int nn = __shfl(n, src, WAVE), vv = __shfl(i, src, WAVE);
+            const int nn = __shfl(n, src, WAVE), vv = __shfl(i, src, WAVE), rm = __shfl(room, src, WAVE);
             const int zid = zmarks_find(Z, counters, vv);
             const int *row = zid >= 0 ? Z.rows + (size_t)zid * Z.stride : nullptr;
             // its membership bitmap (hot mode) is rebuilt with the list: nobody reads it in this launch (crossing
@@ -1876,7 +1992,10 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
                 }
                 base += __popcll(bm);
             }
-            if (lane == 0) { P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; if (lb) atomicOr(&lb[facet >> 5], 1u << (facet & 31)); }
+            if (lane == 0) {
+                P.pool[on + base] = facet; P.inc_off[vv] = on; P.inc_len[vv] = base + 1; if (lb) atomicOr(&lb[facet >> 5], 1u << (facet & 31));
+                if (rm > 0) P.capx[vv] = ((unsigned long long)on << 32) | (unsigned)rm;       // (moved: the room reserved for it, slack included)
+            }
         }
     }
     if (!valid) return;
@@ -1900,6 +2019,7 @@ __global__ __launch_bounds__(PB) void k_emit2(PolyView P, Hp hp, int facet, cons
     P.pool[off_new + m++] = facet;
     P.inc_off[i] = off_new;
     P.inc_len[i] = m;
+    relist_bitmap(P, i, off_new, m);
 }
 
 // ---- K2 in ONE workgroup: the adjacency prune over the members of the new facet (bslv_poly.c:482-540) ----
@@ -1957,7 +2077,7 @@ __device__ __forceinline__ void k2_for_entries(const int *pool, int nm, const un
 // NWC = compile-time bound of the row length in words, so the accumulator stays in registers.
 template <int NWC>
 __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const unsigned long long *bits, const unsigned long long *rows, unsigned *adj_bits,
-                                         int (*queue)[128])
+                                         int (*queue)[128], const unsigned long long *later = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the row intersection of one candidate
@@ -1994,9 +2114,10 @@ __device__ __forceinline__ void k2_pairs(int nm, int d, int W, int NW, const uns
             bool cand = false;
             if (j < nm) {
                 int nmut = 0;
-                for (int w = 0; w < W; w++) nmut += __popcll(bits[w * nm + i] & bits[w * nm + j]);
+                unsigned long long lat = 0ull;       // (rounds) a mutual facet of a LATER cut of the round: that cut's prune has the final word on this pair
+                for (int w = 0; w < W; w++) { const unsigned long long x = bits[w * nm + i] & bits[w * nm + j]; nmut += __popcll(x); if (later) lat |= x & later[w]; }
                 if (d == 1) atomicOr(&adj_bits[(rowbase + j) >> 5], 1u << ((rowbase + j) & 31));
-                else cand = nmut >= d - 1;
+                else cand = nmut >= d - 1 && lat == 0ull;
             }
             const unsigned long long bm = __ballot(cand);
             if (bm == 0ull) continue;
@@ -2026,6 +2147,18 @@ struct K2V2 {
     int *fc2, *fl2, *fc_ticket; int fc_slices, fc_stride;
 };
 __device__ __forceinline__ int k2v2_round(const RState *st);
+__device__ __forceinline__ int k2v2_rank_base(const RState *st);
+// is element v (owner code co = cutof[v]) a member of the new facet of rank `want`?  A shared on-plane element (co = -1 - k) carries the
+// ranks of its k cuts at the end of its rebuilt list, ascending.
+__device__ __forceinline__ bool k2v2_member(const PolyView &P, int v, int co, int vs, int want)
+{
+    if (co >= -1) return co == vs;
+    const int k = -1 - co;
+    const int *tail = P.pool + P.inc_off[v] + P.inc_len[v] - k;
+    bool mine = false;
+    for (int t = 0; t < k; t++) mine |= tail[t] == want;
+    return mine;
+}
 __device__ __forceinline__ void k2v2_sizes(const RState *st, int &S, int &go, int &nzero, int &nv0, int &ncross);
 __device__ void k2v2_check_members(const K2V2 &V, int vs, const int *s_mem, int nm, const int *members, int nzero);
 // (a device function: the kernel of the single-cut pipeline, k2_fused_t<false>, and the prune launch of a round, k_r2_k2, call it)
@@ -2075,6 +2208,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
     const int tid = threadIdx.x, d = P.d;
     int nm = nzero + ncross;
     const int vs = (int)blockIdx.x;                 // V2: the selected cut of this workgroup
+    const int myrank = V2 ? k2v2_rank_base(V.st) + vs : 0x7FFFFFFF;      // ... and the rank of its facet
     // V2: fallback request / empty result of cut vs (uniform callers)
     auto v2_result = [&](int cnt, int n) { if (tid == 0) { V.cnt_g[vs] = cnt; V.nm_g[vs] = n; } };
     if (V2) {
@@ -2086,7 +2220,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
         for (int c0 = 0; c0 < ncand; c0 += K2T) {
             const int c = c0 + tid;
             int v = -1;
-            if (c < ncand) { v = c < nzero ? members[c] : nv0 + (c - nzero); if (V.cutof[v] != vs) v = -1; }
+            if (c < ncand) { v = c < nzero ? members[c] : nv0 + (c - nzero); if (!k2v2_member(P, v, V.cutof[v], vs, myrank)) v = -1; }
             Tri t{v >= 0, 0, 0};
             Tri tot;
             const Tri ex = block_exscan(t, &tot, lds);
@@ -2181,7 +2315,8 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
     K2_PHASE(2);
     const int W = (s_nloc + 63) >> 6, NW = (nm + 63) >> 6;
     unsigned long long *rows = bits + W * nm;        // rows[f * NW + k]: members on local facet f
-    if (V2 && (long long)W * nm + (long long)W * 64 * NW > bcap) {
+    unsigned long long *later = rows + W * 64 * NW;  // (V2) later[w]: local facets of LATER cuts of this round (shared on-plane members carry them)
+    if (V2 && (long long)W * nm + (long long)W * 64 * NW + W > bcap) {
         if (!use_hash) k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
         v2_result(-4, nm);
         return;
@@ -2191,7 +2326,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
         if (tid == 0) { Tri r{0, 1, 0}; totals[0] = r; if (ne_dev) *ne_dev = ebase; if (abort_flag) *abort_flag = 1; mail->t = r; mail->seq = seq; }
         return;
     }
-    for (int w = tid; w < W * nm + W * 64 * NW; w += K2T) bits[w] = 0ull;
+    for (int w = tid; w < W * nm + W * 64 * NW + (V2 ? W : 0); w += K2T) bits[w] = 0ull;
     __syncthreads();
     // P3
     if (use_hash)
@@ -2201,6 +2336,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
             const int id = v & 0x3FFFFFFF;
             atomicOr(&bits[(id >> 6) * nm + m], 1ull << (id & 63));
             atomicOr(&rows[id * NW + (m >> 6)], 1ull << (m & 63));
+            if (V2 && g > myrank) atomicOr(&later[id >> 6], 1ull << (id & 63));
         });
     else
         k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int m, int g) {
@@ -2208,16 +2344,18 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
             const int id = __hip_atomic_load(&flocal[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicOr(&bits[(id >> 6) * nm + m], 1ull << (id & 63));
             atomicOr(&rows[id * NW + (m >> 6)], 1ull << (m & 63));
+            if (V2 && g > myrank) atomicOr(&later[id >> 6], 1ull << (id & 63));
         });
     __syncthreads();
     // the global counts go back to zero for the next cut (plain stores, nothing waits for them)
     if (!use_hash) k2_for_entries(P.pool, nm, s_off, s_len, s_islong, s_long, nlong, [&](int, int g) { fcount[g] = 0; });
     K2_PHASE(3);
     // P4+P5 (k2_pairs)
-    if (NW <= 1) k2_pairs<1>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
-    else if (NW <= 2) k2_pairs<2>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
-    else if (NW <= 4) k2_pairs<4>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
-    else k2_pairs<K2_MAXNM / 64>(nm, d, W, NW, bits, rows, adj_bits, s_queue);
+    const unsigned long long *lat = V2 ? later : nullptr;
+    if (NW <= 1) k2_pairs<1>(nm, d, W, NW, bits, rows, adj_bits, s_queue, lat);
+    else if (NW <= 2) k2_pairs<2>(nm, d, W, NW, bits, rows, adj_bits, s_queue, lat);
+    else if (NW <= 4) k2_pairs<4>(nm, d, W, NW, bits, rows, adj_bits, s_queue, lat);
+    else k2_pairs<K2_MAXNM / 64>(nm, d, W, NW, bits, rows, adj_bits, s_queue, lat);
     __syncthreads();
     K2_PHASE(4);
     K2_PHASE(5);
@@ -2632,6 +2770,7 @@ __device__ void k2v2_check_members(const K2V2 &V, int vs, const int *s_mem, int 
             }
 }
 __device__ __forceinline__ int k2v2_round(const RState *st) { return st->round; }
+__device__ __forceinline__ int k2v2_rank_base(const RState *st) { return st->rank_base; }
 __device__ __forceinline__ void k2v2_sizes(const RState *st, int &S, int &go, int &nzero, int &nv0, int &ncross)
 {
     S = st->S; go = st->go && !r2_halted(st); nzero = st->nzero; nv0 = st->nv; ncross = st->ncross;
@@ -2651,6 +2790,7 @@ struct bslv_poly {
     int r2_fuse = 0;                  // (default 0: measured fastest) 1: the classification of a round's new vertices rides in the launch of its prunes (extra workgroups); 2: and the last prune workgroup to finish writes the adjacent pairs (a ticket; measured slower); 0: three launches (BSLV_R2_FUSE / debug_set key 13)
     bool r2_spec = true;              // rounds are queued one ahead of the host (BSLV_R2_SPEC=0 / debug_set key 12: the host reads every round's mailbox before it queues the next)
     long r2_spec_void = 0;            // rounds that were queued ahead and found the device halted (bslv_poly_rounds2_stats)
+    bool r2_share = true;             // (round 4) the cuts of a round may share elements that lie ON their planes: only a MINUS element makes two cuts conflict (poly_rounds2_kernels.inc, "Elements shared by the cuts of a round"); BSLV_R2_SHARE=0 / debug_set key 15: an element belongs to one cut of a round (rounds 2-3)
     bool r2_mis = true;               // rounds take a MAXIMAL independent set from a conflict matrix of the chunk (round 3); BSLV_R2_MIS=0 / debug_set key 11: the local minima of one random order (round 2)
     int chunk_cuts = 1024;             // cuts classified and applied together (bslv_poly_debug_set(h, 7, n); at most 4096)
     int r2_defer = 0;                 // rounds of a chunk stop when one holds fewer cuts than this; what is left is handed BACK to the caller (rc 2) -- see bslv_poly_set_defer
@@ -2805,6 +2945,7 @@ static int ensure_vcap(bslv_poly *h, int need)
     if ((rc = grow(&P.cls, h->nv, ncap, h->stream))) return rc;   // classes of the cut in flight survive a re-allocation
     if ((rc = grow(&P.inc_off, h->nv, ncap, h->stream))) return rc;
     if ((rc = grow(&P.inc_len, h->nv, ncap, h->stream))) return rc;
+    if ((rc = grow(&P.capx, h->nv, ncap, h->stream, true))) return rc;            // (zero = no slack recorded: relied upon)
     if ((rc = grow(&h->members, (size_t)P.cap, ncap, h->stream))) return rc;     // kept: a prune waiting for its fallback still needs its members
     {   // membership-bitmap slots: -1 everywhere except on the long elements of a hot chunk
         const int old = h->lslotcap;
@@ -3498,6 +3639,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (getenv("BSLV_NO_HOT")) h->hot_enabled = false;
     if (getenv("BSLV_NO_ROUNDS2")) h->rounds2_enabled = false;
     if (const char *e = getenv("BSLV_R2_MIS")) h->r2_mis = atoi(e) != 0;
+    if (const char *e = getenv("BSLV_R2_SHARE")) h->r2_share = atoi(e) != 0;
     if (const char *e = getenv("BSLV_R2_SPEC")) h->r2_spec = atoi(e) != 0;
     if (const char *e = getenv("BSLV_R2_FUSE")) h->r2_fuse = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("BSLV_CHUNK_CUTS")) h->chunk_cuts = std::min(4096, std::max(32, atoi(e)));
@@ -3539,7 +3681,7 @@ void bslv_poly_destroy(bslv_poly *h)
         (void)hipFree(h->k2dbg);
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
-    fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.pool); fr(h->P.keep);
+    fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.capx); fr(h->P.pool); fr(h->P.keep);
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->fm_cnt); fr(h->fm_list); fr(h->nzlist); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
@@ -4009,6 +4151,7 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 10: h->shard_min = (int)std::max(2L, value); return 0;           /* multi-GPU: facets from this size on have their pair space dealt to the ranks */
     case 13: h->r2_fuse = (int)std::min(2L, std::max(0L, value)); return 0;                           /* one launch for a round's prunes + classification + pair emission (1) / three (0) */
     case 12: h->r2_spec = value != 0; return 0;                           /* rounds queued one ahead of the host (1) / mailbox read before every round (0) */
+    case 15: h->r2_share = value != 0; return 0;                          /* rounds: cuts may share on-plane elements (1) / every element belongs to one cut of a round (0) */
     case 11: h->r2_mis = value != 0; return 0;                            /* rounds: maximal independent set from the conflict matrix (1) / local minima of one order (0) */
     case 9: g_k1_mfma = value != 0; return 0;                            /* incidence kernel K1 on the matrix pipe from 16 halfspaces on (1) or the scalar kernel (0, default); process-wide */
     case 14: h->r2_defer = (int)std::max(0L, value); return 0;           /* see bslv_poly_set_defer */
