@@ -69,6 +69,7 @@ struct bslv_benson {
     int defer_thr = getenv("BSLV_DEFER") ? std::max(0, atoi(getenv("BSLV_DEFER"))) : 0, defer_max = 512;
     long tot_deferred = 0, defer_flushes = 0;
     long fam_fallbacks = 0;                           // batches that one family would have filled: taken newest first
+    long dir_only_windows = 0;                        // policy 6: chosen families that held nothing but extreme directions (chosen again at once)
     double facet_z0 = getenv("BSLV_FACET_Z0") ? atof(getenv("BSLV_FACET_Z0")) : (double)INFINITY;
     std::deque<int> batch_f0;                         // first dual slot of each of the last outer iterations
     std::vector<double> facet_normal;                 // q per dual slot (zeros where unknown)
@@ -318,7 +319,9 @@ static int collect_impl(bslv_benson *h, int ctx, int max_batch, int rank, int wo
     h->rank = rank; h->world = world;
     max_batch = (int)std::min<long long>(max_batch, (long long)h->batch_cap * world);          // (what the pool of tableaux can serve, see bslv_benson_create_ex)
     int rc, cnt = 0;
-    if (h->policy == 6) {
+    if (h->policy == 6) for (int again = 0;; again++) {
+        // (again: the families chosen held nothing but extreme directions -- marked as processed below -- while vertices are still
+        // waiting elsewhere: choose again, as the generic path does; a caller that stops on an empty batch would otherwise stop early)
         B.b_idx.clear(); B.b_val.clear(); B.b_parent.clear(); B.b_front.clear();
         const int nf = bslv_poly_ndual(h->poly);
         h->collect_seq++;
@@ -382,8 +385,8 @@ static int collect_impl(bslv_benson *h, int ctx, int max_batch, int rank, int wo
         // taken newest first, as rounds 1-2 did (S-degenerate q = 10, three steps: 17 -> 134 LPs/s; BSLV_FAM_FALLBACK=0: never)
         static const bool fam_fallback = !(getenv("BSLV_FAM_FALLBACK") && atoi(getenv("BSLV_FAM_FALLBACK")) == 0);
         const bool one_family = fam_fallback && !chosen.empty() && counts[chosen[0] - f_lo] >= max_batch;
-        if (one_family) h->fam_fallbacks++;
-        else {
+        if (one_family) { h->fam_fallbacks++; break; }       // (the generic path below)
+        {
         // (with a cap on the children of one cut the device hands over the whole families and the host thins them out)
         const int fetch = h->fam_cap > 0 ? (int)std::min<long long>(std::max<long long>(full, 1), 16LL * max_batch) : max_batch;
         std::vector<int> idx(fetch), ideal(fetch), parent(fetch);
@@ -416,7 +419,7 @@ static int collect_impl(bslv_benson *h, int ctx, int max_batch, int rank, int wo
         }
         if (!dirs.empty() && (rc = bslv_poly_mark(h->poly, (int)dirs.size(), dirs.data()))) return rc;
         h->unprocessed_left = total - nkept;
-        // (a window that held only directions: the next call sees them marked)
+        if (B.b_idx.empty() && !dirs.empty() && h->unprocessed_left > 0 && again < 256) { h->dir_only_windows++; continue; }
         return deal_batch(h, B, rank, world, n_local, n_total);
         }
     }
@@ -838,7 +841,7 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     const int f0 = bslv_poly_ndual(h->poly);
     // thin rounds hand their cuts back only while a later call is certain (new LPs in this one) and the backlog is small
     // (and the batch is large -- small batches have nothing but thin rounds; every waiting cut also holds a tableau of the pool)
-    const int thr = (nrec >= 512 && !h->mark_at_collect && ncut - (int)cut_src.size() < std::min(h->defer_max, h->pool_slots / 8)) ? h->defer_thr : 0;
+    const int thr = (nrec >= 512 && h->world == 1 && !h->mark_at_collect && ncut - (int)cut_src.size() < std::min(h->defer_max, h->pool_slots / 8)) ? h->defer_thr : 0;
     if ((rc = bslv_poly_set_defer(h->poly, thr))) return rc;
     if (ncut && (rc = bslv_poly_add_cuts(h->poly, ncut, cuts.data(), nullptr, prc.data()))) return rc;
     // bookkeeping: facet ids f0.. were assigned in this order on every rank

@@ -908,6 +908,7 @@ struct bslv_lpq {
     // over a_ij whenever the bound the column sits on is the row's and not its own.
     struct Presolve {
         int M0 = 0, N0 = 0, nfold = 0;                 // the model as given; rows folded
+        bool empty_box = false;                         // bounds set later made the box of a folded row's column empty: every LP is infeasible (the row would have said so)
         std::vector<int> row_in;                       // given row -> row of the engine's model, or -1 (folded)
         std::vector<int> fold_col;                     // given row -> column it bounds (folded rows)
         std::vector<double> fold_a;                    //              its coefficient
@@ -1133,7 +1134,13 @@ static void fold_bounds(bslv_lpq *h, const double *lb, const double *ub, std::ve
         if (l > P.clo[j]) { P.clo[j] = l; P.lo_src[j] = i; }
         if (u < P.cup[j]) { P.cup[j] = u; P.up_src[j] = i; }
     }
-    for (int j = 0; j < N0; j++) { lo[Mi + j] = P.clo[j]; up[Mi + j] = P.cup[j]; }
+    // new bounds may leave a folded row no room (the fold set is fixed at create time): the model as given is infeasible -- reported as
+    // such by solve_batch; the engine itself gets a consistent (degenerate) box
+    P.empty_box = false;
+    for (int j = 0; j < N0; j++) {
+        if (P.clo[j] > P.cup[j] + TOL_BND * (1.0 + fabs(P.cup[j]))) { P.empty_box = true; P.cup[j] = P.clo[j]; }
+        lo[Mi + j] = P.clo[j]; up[Mi + j] = P.cup[j];
+    }
 }
 int bslv_lpq_set_bounds(bslv_lpq *h, const double *lb, const double *ub)
 {
@@ -1166,7 +1173,9 @@ int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double 
             int nz = 0, jj = -1;
             const double *row = A + (size_t)i * N;
             for (int j = 0; j < N && nz < 2; j++) if (row[j] != 0.0) { nz++; jj = j; }
-            if (nz == 1) {
+            // (a column whose bounds are given per LP keeps its rows: solve_batch would overwrite the folded bound)
+            const bool col_per_lp = nz == 1 && var_cnt > 0 && M + jj >= var_first && M + jj < var_first + var_cnt;
+            if (nz == 1 && !col_per_lp) {
                 const double a = row[jj];
                 const double l = std::max(clo[jj], a > 0 ? lb[i] / a : ub[i] / a), u = std::min(cup[jj], a > 0 ? ub[i] / a : lb[i] / a);
                 if (l <= u) { fold = true; clo[jj] = l; cup[jj] = u; P.fold_col[i] = jj; P.fold_a[i] = a; }      // (an empty box stays a row: the LP reports it)
@@ -1243,6 +1252,11 @@ int bslv_lpq_solve_batch_obj(bslv_lpq *h, int B, const int *src, const int *dst,
 static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo, const double *vup,
                             int cfirst, int ccnt, const double *cvals, int *status, int *iters)
 {
+    if (h && h->ps.empty_box && B > 0 && status) {        // (bslv_lpq_set_bounds left a folded row no room: fold_bounds)
+        for (int b = 0; b < B; b++) { status[b] = BSLV_LP_INFEASIBLE; if (iters) iters[b] = 0; }
+        h->last_iters = 0; h->last_pivots = 0; h->last_passes = 0;
+        return 0;
+    }
     if (!h || B < 0 || (B > 0 && (!src || !dst)) || (B > 0 && h->L.vcnt > 0 && (!vlo || !vup))) {
         set_error("bslv_lpq_solve_batch: bad argument");
         return BSLV_E_ARG;

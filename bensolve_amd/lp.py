@@ -102,6 +102,11 @@ class LpEngine:
     def reset_slot(self, slot):
         check(self.lib.bslv_lpq_reset_slot(self.h, slot))
 
+    def rows_folded(self):
+        import ctypes
+        self.lib.bslv_lpq_rows_folded.argtypes = [ctypes.c_void_p]
+        return int(self.lib.bslv_lpq_rows_folded(self.h))
+
     def set_bounds(self, lo, up):
         lo = np.ascontiguousarray(lo, np.float64)
         up = np.ascontiguousarray(up, np.float64)

@@ -475,3 +475,26 @@ def test_families_of_unprocessed_vertices():
     pts = ideal[:n.value] == 0
     assert np.abs(val[:n.value][pts] @ w - y[-1]).max() < 1e-7
     eng.close()
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3])
+def test_families_that_hold_only_directions_do_not_end_the_run_early(batch):
+    """The default batch rule (whole families, bslv_benson_set_families) with a batch so small that the families chosen first hold
+    nothing but the extreme directions of the upper image: collect marks them and must choose AGAIN instead of returning an empty
+    batch while vertices wait (a caller keyed on 'nothing collected' -- PipelinedStepper.run, bslv_algs.c:1032-1035's
+    poly__get_vrtx == EXIT_FAILURE -- would stop with an incomplete image)."""
+    from bensolve_amd.benson import PipelinedStepper
+    prob = synth.covering_vlp(30, 15, 3, 5)
+    rc, fp, st = oracle_api.benson_phase2_primal(prob, eps=1e-9)
+    fp.dual_adjacency()
+    exp = ph.canonical(fp.dump(), decimals=6)
+    fp.close()
+    eng = BensonEngine(prob, eps=1e-9, pool_slots=128)
+    assert eng.start() == 0
+    PipelinedStepper(eng, batch).run()
+    eng.poly_call("dual_adjacency")
+    d = eng.poly_dump()
+    got = ph.canonical(d, decimals=6)
+    assert np.all(d["ps"][d["pu"].astype(bool)] == 1)         # every live element was processed
+    eng.close()
+    ph.assert_benson_results_agree(got, exp)

@@ -499,3 +499,48 @@ def test_one_selection_launch_per_pass_is_bit_identical_to_six(monkeypatch, kind
     assert a[1].sum() > B, "the batch needs pivots for this to mean anything"
     for x, y in zip(a[2:], b[2:]):
         assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+
+
+def test_bounds_that_leave_a_folded_row_no_room_are_reported_infeasible():
+    """The presolve folds a row with one non-zero into its column's bounds once, at create time.  New bounds (bslv_lpq_set_bounds:
+    lp_set_rows / lp_set_cols of the reference, bslv_lp.c:112-135) that make the folded row and its column contradict each other
+    leave no row behind that could say so: the engine must report INFEASIBLE itself, and recover when the bounds are relaxed."""
+    # min x0 + x1  s.t.  row0: x0 + x1 >= 1,  row1: 2 x0 in [0, 4] (one non-zero: folded),  x >= 0
+    A = np.array([[1.0, 1.0], [2.0, 0.0]])
+    lo = np.array([1.0, 0.0, 0.0, 0.0]); up = np.array([np.inf, 4.0, np.inf, np.inf])
+    eng = LpEngine(2, 2, A, lo, up, np.array([0.0, 1.0, 1.0]), 0, 0, 4)
+    assert eng.rows_folded() == 1
+    eng.reset_slot(0)
+    st, _ = eng.solve_batch([0], [0], np.zeros((1, 0)), np.zeros((1, 0)))
+    assert st[0] == 4 and abs(eng.obj([0])[0] - 1.0) < 1e-12
+    # row1 now demands 2 x0 >= 6 while the column says x0 <= 2: infeasible in the model as given
+    lo2, up2 = lo.copy(), up.copy()
+    lo2[1], up2[1], up2[2] = 6.0, 8.0, 2.0
+    eng.set_bounds(lo2, up2)
+    eng.reset_slot(0)
+    st, _ = eng.solve_batch([0], [0], np.zeros((1, 0)), np.zeros((1, 0)))
+    assert st[0] == 0, st
+    # relaxed again (x0 <= 5): feasible, x0 = 3 forced by the folded row, objective 3
+    up2[2] = 5.0
+    eng.set_bounds(lo2, up2)
+    eng.reset_slot(0)
+    st, _ = eng.solve_batch([0], [0], np.zeros((1, 0)), np.zeros((1, 0)))
+    assert st[0] == 4 and abs(eng.obj([0])[0] - 3.0) < 1e-9, (st, eng.obj([0]))
+    eng.close()
+
+
+def test_a_row_on_a_column_with_per_lp_bounds_is_not_folded():
+    """A single-variable row whose column gets its bounds PER LP (the var range of solve_batch lies on columns) must stay a row:
+    folded into the column's bounds it would be overwritten by the bounds of every LP."""
+    # min -x0  s.t.  row0: x0 <= 1 (one non-zero),  row1: x0 + x1 >= 0;  per-LP bounds on column x0
+    A = np.array([[1.0, 0.0], [1.0, 1.0]])
+    lo = np.array([-np.inf, 0.0, 0.0, 0.0]); up = np.array([1.0, np.inf, 10.0, np.inf])
+    eng = LpEngine(2, 2, A, lo, up, np.array([0.0, -1.0, 0.0]), 2, 1, 4)      # var range = column 0 (variable id M + 0 = 2)
+    assert eng.rows_folded() == 0
+    eng.reset_slot(0)
+    st, _ = eng.solve_batch([0], [0], np.array([[0.0]]), np.array([[5.0]]))       # cold start, then the batch from its basis
+    assert st[0] == 4, st
+    st, _ = eng.solve_batch([0, 0], [1, 2], np.array([[0.0], [0.0]]), np.array([[5.0], [0.5]]))
+    assert np.all(st == 4), st
+    np.testing.assert_allclose(eng.obj([1, 2]), [-1.0, -0.5], rtol=0, atol=1e-12)     # the row x0 <= 1 holds although LP 1 says x0 <= 5
+    eng.close()
