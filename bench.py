@@ -20,6 +20,7 @@ torch.distributed.run, one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
               simplex, 1 core) on the first LPs of the same workload, rank 0, N=1 only.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -124,11 +125,16 @@ def main():
 
     pipe = None
     phase_ms = [0.0, 0.0, 0.0]          # host wall clock of collect / LP batch / cut application (N=1, unpipelined)
+    dist_ms = [0.0, 0.0, 0.0, 0.0]      # N > 1, this rank: collect / its LPs / all-gather (waits for the slowest rank) / application of ALL ranks' cuts
 
     def one_step():
         if world > 1:
             s = eng.step(B * world)              # (bslv_benson_step_dist: collect -> this rank's LPs -> all-gather -> apply)
             s.update(n_total=s["lps"])
+            ph4 = (ctypes.c_double * 4)()
+            eng.lib.bslv_dist_last_phases(ph4)
+            for k in range(4):
+                dist_ms[k] += ph4[k]
             return s
         if pipe is not None:
             s = pipe.step()
@@ -169,6 +175,7 @@ def main():
 
     eng.lp_call("set_profile", True)
     phase_ms[:] = [0.0, 0.0, 0.0]
+    dist_ms[:] = [0.0, 0.0, 0.0, 0.0]
     rounds0 = eng.poly_call("rounds_run")
     ps0 = eng.poly_call("path_stats")
     r2s0 = eng.poly_call("rounds2_stats")
@@ -203,6 +210,7 @@ def main():
     snap["live"] = int(eng.poly_dump()["pu"].sum()) if snap["counts"]["nprimal"] < 5_000_000 else -1
     if rank == 0: print("bench: timed region done (%d steps, %.3f s)" % (args.steps, dt), file=sys.stderr, flush=True)
     phase_timed = list(phase_ms)         # (a copy: one_step() keeps adding to phase_ms if the run goes on below)
+    dist_timed = list(dist_ms)
     # Everything the headline needs is measured.  Two more figures for the reader, outside the timed region (rank 0, one GPU):
     #  * long_window: the SAME run continued to 5x the steps -- S-mid never terminates, the polyhedron keeps growing, and the rate
     #    of the first steps after the ramp is not the rate of a long run;
@@ -247,11 +255,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        agg = torch.tensor([pivots, upd_ms, snap["totals"]["lps"], starts["root"], starts["nearest"]], dtype=torch.float64, device=cdev)
+        agg = torch.tensor([pivots, upd_ms, snap["totals"]["lps"], starts["root"], starts["nearest"]] + dist_timed + [lp_ms], dtype=torch.float64, device=cdev)
         allp = [torch.zeros_like(agg) for _ in range(world)]
         dist.all_gather(allp, agg)
         pivots_all = sum(float(a[0]) for a in allp)
-        per_rank = [{"rank": r, "pivots": int(a[0]), "starts_from_root_tableau": int(a[3]), "starts_from_nearest_tableau": int(a[4])} for r, a in enumerate(allp)]
+        per_rank = [{"rank": r, "pivots": int(a[0]), "starts_from_root_tableau": int(a[3]), "starts_from_nearest_tableau": int(a[4]),
+                     "phase_ms_per_step": {"collect": round(float(a[5]) / args.steps, 3), "lp": round(float(a[6]) / args.steps, 3), "allgather_incl_wait": round(float(a[7]) / args.steps, 3),
+                                           "cuts_of_all_ranks": round(float(a[8]) / args.steps, 3)}} for r, a in enumerate(allp)]
     else:
         pivots_all = pivots
         per_rank = [{"rank": 0, "pivots": int(pivots), "starts_from_root_tableau": starts["root"], "starts_from_nearest_tableau": starts["nearest"]}]
@@ -285,12 +295,15 @@ def main():
     # second figure of merit: the cut phase (bslv_poly's half of the path).  Not HBM-bound (integer / LDS /
     # latency): reported as time per cut, cuts per pass over the polyhedron, and pair tests per second next to the
     # reference's own bslv_poly.c on one core (6.9e6/s at q=5, N=1000).
-    cut_ms = phase_timed[2]
+    cut_ms = phase_timed[2] if world == 1 else dist_timed[3]       # (N > 1: every rank applies the cuts of ALL ranks: rank 0's clock)
     passes_poly = snap["rounds_run"] - rounds0
     ps = snap["path_stats"]
     roofline_cuts = {"bound": "latency/integer (not hbm)", "kernels": "per round of independent cuts: k_r2_minit (conflict matrix, LDS) + k_r2_select3 (maximal independent set) + k_r2_assign3 + k_flags2 + k_r2_emit + k_r2_classify3 + k2_fused_t<true> (one prune per selected cut) + k_r2_k2emit; k_flags2+k_emit2+k2_fused per single cut",
                      "cuts_applied": cuts, "cuts_per_step": round(cuts / max(args.steps, 1), 1),
-                     "us_per_cut": round(cut_ms * 1e3 / max(cuts, 1), 2) if world == 1 and pipe is None else None,
+                     "us_per_cut": round(cut_ms * 1e3 / max(cuts, 1), 2) if pipe is None else None,
+                     "lps_per_cut": round(lps / max(cuts, 1), 3),
+                     "scaling_ceiling_lps_per_sec": round((lps / max(cuts, 1)) / (cut_ms * 1e-3 / max(cuts, 1)), 1) if pipe is None and cut_ms > 0 else None,
+                     "scaling_ceiling_note": "the cut phase is replicated: every rank applies the cuts of ALL ranks, so the whole-job rate at ANY number of GPUs stays below LPs per cut / seconds per cut of one replica (this figure) -- the LP phase is the only part that shards",
                      "passes_over_polyhedron": passes_poly, "cuts_per_pass": round(cuts / max(passes_poly, 1), 2),
                      "single_cut_pipeline_cuts": ps["single_cuts"] - ps0["single_cuts"], "hot_chunks": ps["hot_chunks"] - ps0["hot_chunks"],
                      "pair_tests_per_sec": round(pair_tests / dt, 1), "reference_pair_tests_per_sec_1core": 6.9e6,
@@ -398,7 +411,8 @@ def main():
                        "tableau_slot_bytes": slot_bytes, "pool_slots": pool_slots, "batch_policy": args.policy or "6 (library default: whole families, children of the shallowest cuts of the last batch first)", "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
-            "live_vertices": live, "poly_rounds": snap["rounds_run"] - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": {"collect": round(phase_timed[0] / args.steps, 2), "lp": round(phase_timed[1] / args.steps, 2), "cuts": round(phase_timed[2] / args.steps, 2)}, "update_kernel_ms_rank0": round(upd_ms, 2),
+            "live_vertices": live, "poly_rounds": snap["rounds_run"] - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": ({"collect": round(phase_timed[0] / args.steps, 2), "lp": round(phase_timed[1] / args.steps, 2), "cuts": round(phase_timed[2] / args.steps, 2)} if world == 1 else
+                                   {"collect": round(dist_timed[0] / args.steps, 2), "lp": round(dist_timed[1] / args.steps, 2), "allgather_incl_wait": round(dist_timed[2] / args.steps, 2), "cuts": round(dist_timed[3] / args.steps, 2), "note": "rank 0; every rank in warm_starts.per_rank"}), "update_kernel_ms_rank0": round(upd_ms, 2),
             "warm_starts": {"per_rank": per_rank, "note": "LPs whose parent's tableau was not resident on the rank that solved them start from the nearest resident tableau (else from the root tableau): the hit rate of the dealing rule"},
             "useful_vs_cpu_baseline": round(((cuts + confirmed) / dt) / cpu["value"], 1) if cpu and cpu.get("value") else None,
             "long_window": long_window,

@@ -160,6 +160,7 @@ int bslv_dist_stats(long *gathers, double *ms)
 // One outer iteration over all ranks: the batch (max_batch_global vertices) is dealt to the ranks, each rank solves its shard,
 // the records are all-gathered as fixed-size blocks [count ; records ; zero padding], every rank applies all of them.
 // stats / ms as bslv_benson_step (stats[0] = LPs of ALL ranks); additionally ms[1] includes the exchange.
+static double g_phase[4] = {0, 0, 0, 0};
 int bslv_benson_step_dist(bslv_benson *h, int max_batch_global, long *stats, double *ms)
 {
     if (!h || max_batch_global < 1) return BSLV_E_ARG;
@@ -182,6 +183,7 @@ int bslv_benson_step_dist(bslv_benson *h, int max_batch_global, long *stats, dou
     block[1] = rc_local;
     auto t2 = std::chrono::steady_clock::now();
     if ((rc = bslv_dist_allgather(block.data(), all.data(), (cap + 1) * RL))) return rc;
+    auto tg = std::chrono::steady_clock::now();
     for (int r = 0; r < world; r++) {
         const int st_r = (int)all[(size_t)r * (cap + 1) * RL + 1];
         if (st_r) {
@@ -210,6 +212,19 @@ int bslv_benson_step_dist(bslv_benson *h, int max_batch_global, long *stats, dou
         ms[1] = std::chrono::duration<double, std::milli>(t3 - t2).count() + std::chrono::duration<double, std::milli>(t1 - t0).count();
         ms[2] = std::chrono::duration<double, std::milli>(t3 - t0).count();
     }
+    // the four phases of this rank's step, for the scaling report (bslv_dist_last_phases): the all-gather includes the wait for the slowest rank's LPs
+    g_phase[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    g_phase[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    g_phase[2] = std::chrono::duration<double, std::milli>(tg - t2).count();
+    g_phase[3] = std::chrono::duration<double, std::milli>(t3 - tg).count();
+    return 0;
+}
+// host wall clock of the phases of the last bslv_benson_step_dist on this rank, ms: [0] collect (choice and dealing of the batch),
+// [1] this rank's LPs, [2] the all-gather of the cut records (waits for the slowest rank), [3] application of ALL ranks' cuts (replicated)
+int bslv_dist_last_phases(double out[4])
+{
+    if (!out) return BSLV_E_ARG;
+    for (int k = 0; k < 4; k++) out[k] = g_phase[k];
     return 0;
 }
 

@@ -314,6 +314,9 @@ int  bslv_dist_world(void);
 int  bslv_dist_allgather(const double *send, double *recv, int count_per_rank);   /* host buffers; recv holds world * count */
 int  bslv_dist_stats(long *gathers, double *ms);
 int  bslv_benson_step_dist(bslv_benson *h, int max_batch_global, long *stats /* 8 */, double *ms /* 3 */);
+/* host wall clock (ms) of the phases of the last bslv_benson_step_dist on this rank: collect, this rank's LPs, all-gather of the
+ * records (includes the wait for the slowest rank), application of all ranks' cuts (replicated on every rank) */
+int  bslv_dist_last_phases(double out[4]);
 
 /* ------------------------------------------------------------------------------------------
  * 4b. The callers around phase 2: ordering cone data (sol_init, bslv_vlp.c:599-864), cone_vertenum

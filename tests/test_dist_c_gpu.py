@@ -179,3 +179,50 @@ def test_two_ranks_keep_their_warm_starts():
     print("pivots per LP: one rank %.2f, two ranks %.2f | cuts per pass %.2f / %.2f | starts of the two ranks: %s %s" % (ppl1, ppl2, cpp1, cpp2, out[0]["starts"], out[1]["starts"]))
     assert ppl2 <= 2.0 * ppl1 + 1.0, (ppl1, ppl2)
     assert cpp2 >= 0.8 * cpp1, (cpp1, cpp2)
+
+
+def _smid_worker(rank, world, port, batch, steps, out):
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dist_init_callback(dist)
+    eng = BensonEngine(synth.CONFIGS["S-mid"](), eps=1e-7, pool_slots=2 * batch + 64)
+    assert eng.start() == 0
+    lps = cuts = piv = 0
+    for _ in range(steps):
+        s = eng.step(batch * world)
+        lps += s["lps"]; cuts += s["cuts"]; piv += s["pivots"]
+    d = eng.poly_dump()
+    h = hashlib.sha256()
+    for k in ("pu", "pi", "ps", "E", "I", "X", "du", "Y"):
+        h.update(k.encode()); h.update(np.ascontiguousarray(d[k]).tobytes())
+    ph4 = (ctypes.c_double * 4)()
+    eng.lib.bslv_dist_last_phases(ph4)
+    out[rank] = dict(sha=h.hexdigest(), lps=lps, cuts=cuts, local_pivots=piv, nprimal=int(len(d["pu"])), live=int(d["pu"].sum()), nedges=int(len(d["E"])), phases=list(ph4),
+                     starts=eng.start_stats())
+    eng.close()
+    dist_finalize()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_at_the_size_of_the_headline_stay_bit_identical():
+    """BASELINE configs[3] in small: S-mid (q = 5, n = 500, m = 1000) as stated, two ranks (two processes sharing the test box's GPU,
+    callback transport), 1024 LPs per rank and step, 10 steps: the replicas of the polyhedron are the same bit for bit -- slots,
+    flags, coordinates, incidence pairs and the edge list in order (SHA-256 over the raw dump) -- both ranks solved LPs, and the
+    phase clocks of the distributed step (bslv_dist_last_phases, what bench.py --gpus N reports per rank) are filled in."""
+    import torch.multiprocessing as mp
+    batch, steps = 1024, 10
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_smid_worker, args=(2, port, batch, steps, out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert a["sha"] == b["sha"], (a, b)
+    assert a["lps"] == b["lps"] > 5 * batch and a["cuts"] == b["cuts"] > 0 and a["nprimal"] == b["nprimal"] and a["nedges"] == b["nedges"]
+    assert a["local_pivots"] > 0 and b["local_pivots"] > 0
+    for r in (a, b):
+        assert len(r["phases"]) == 4 and r["phases"][1] > 0 and r["phases"][3] > 0, r["phases"]
