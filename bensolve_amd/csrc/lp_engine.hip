@@ -77,6 +77,19 @@ struct LpView {
     int *bh, *nh, *nstat, *pos;
     const double *lb, *ub;
     const unsigned char *art;   // bit0: lb is artificial, bit1: ub is artificial
+    // REVISED FORM (round 4; bslv_lpq_create chooses it for wide sparse problems -- ex07 / ex09 of the reference's suite, which hands A
+    // to GLPK as COO, bslv_lp.c:60-70): the matrix of a slot is the BASIS INVERSE B^-1 (M x ldt) instead of the tableau
+    // T = -B^-1 N ((M+1) x ld), A is kept once, as CSC and CSR, for the whole pool.  With K = [I | -A] (column k of K belongs to
+    // variable k: e_k for the auxiliary variable of row k, -A_j for structural j) a basis is B = K[:, bh] and
+    //   row r of the tableau     T[r][j] = -rho . K_nh[j],  rho = row r of B^-1     (one sparse dot product per nonbasic column)
+    //   column q of the tableau  T[:, q] = -B^-1 K_nh[q]                            (a few columns of B^-1)
+    // and a pivot updates B^-1 by the SAME row operations it applies to the tableau -- row r := -rho p, row i -= f_i rho -- so the
+    // delayed update, k_flush and its roofline carry over; only the tableau's column swap (entry q of every row) has no counterpart.
+    // ex09: 171 MB per slot instead of 1.36 GB.  rev == 0: ldt = ld, mrows = M + 1 and everything is as before.
+    int rev, ldt, mrows, probe;  // probe: BSLV_REV_PROBE, timing experiments only (parts of the revised selection skipped: results are WRONG)
+    double *dsl;                // rev: [slots][ld] reduced costs of each slot (the tableau form keeps them as row M of T)
+    const int *cptr, *cidx; const double *cval;   // rev: CSC of A
+    const int *rptr, *ridx; const double *rval;   // rev: CSR of A
 };
 struct BatchView {
     const int *src, *dst;
@@ -96,6 +109,10 @@ struct BatchView {
     const double *cvals;        // [B][ccnt] objective coefficients (objmode)
     int *xstat;                 // [5] of the batch: iterations with bound switches, perturbations, primal steps, removals that left wrong signs, switch iterations carried into beta without a pass
     int *work, *nwork;      // LPs whose tableau k_flush passes over in a round (k_list_pending), their number per round
+    // revised form
+    double *trow;           // [B][ld]   the tableau row of the selection at hand (prow then holds rows of B^-1: [B][KP][ldt])
+    double *uvec;           // [B][ldt]  -K_N x_N: beta = B^-1 uvec (k_rev_u; k_init and the refresh pass of k_flush multiply by it)
+    double *xfull;          // [B][N]    scratch of k_rev_u: values of the nonbasic structurals by column
 };
 
 __device__ __forceinline__ double LO(const LpView &L, const BatchView &Bv, int b, int k)
@@ -122,7 +139,7 @@ __global__ __launch_bounds__(NT) void k_prep(LpView L, BatchView Bv, int B)
     int *bh_d = L.bh + (size_t)dst * L.M, *nh_d = L.nh + (size_t)dst * L.N;
     int *ns_d = L.nstat + (size_t)dst * L.N, *pos_d = L.pos + (size_t)dst * (L.M + L.N);
     double *xN_d = L.xN + (size_t)dst * L.ld;
-    const double *drow_s = L.T + (size_t)src * L.slotT + (size_t)L.M * L.ld;
+    const double *drow_s = L.rev ? L.dsl + (size_t)src * L.ld : L.T + (size_t)src * L.slotT + (size_t)L.M * L.ld;
     if (src != dst) {
         for (int i = threadIdx.x; i < L.M; i += NT) bh_d[i] = bh_s[i];
         for (int i = threadIdx.x; i < L.M + L.N; i += NT) pos_d[i] = pos_s[i];
@@ -201,16 +218,16 @@ __global__ __launch_bounds__(NT) void k_init(LpView L, BatchView Bv, int B)
     int src = Bv.src[b], dst = Bv.dst[b];
     const double *Ts = L.T + (size_t)src * L.slotT;
     double *Td = L.T + (size_t)dst * L.slotT;
-    const double *xN = L.xN + (size_t)dst * L.ld;
+    const double *xN = L.rev ? Bv.uvec + (size_t)b * L.ldt : L.xN + (size_t)dst * L.ld;      // (rev: beta = B^-1 uvec, k_rev_u; beta[M] comes from there too)
     double *beta = L.beta + (size_t)dst * L.Mp1p;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int ld2 = L.ld >> 1;
-    bool copy = (src != dst);
+    int ld2 = L.ldt >> 1;
+    bool copy = (src != dst) && !L.rev;
     for (int rr = wave; rr < TR; rr += NT / WAVE) {
         int i = blockIdx.x * TR + rr;
-        if (i >= L.Mp1) break;
-        const double2 *s = reinterpret_cast<const double2 *>(((L.objmode && i == L.M) ? Td : Ts) + (size_t)i * L.ld);   // (objmode: k_prep wrote the new row M)
-        double2 *d = reinterpret_cast<double2 *>(Td + (size_t)i * L.ld);
+        if (i >= L.mrows) break;
+        const double2 *s = reinterpret_cast<const double2 *>(((L.objmode && i == L.M) ? Td : Ts) + (size_t)i * L.ldt);   // (objmode: k_prep wrote the new row M)
+        double2 *d = reinterpret_cast<double2 *>(Td + (size_t)i * L.ldt);
         const double2 *x2 = reinterpret_cast<const double2 *>(xN);
         double acc = 0.0;
         for (int j2 = lane; j2 < ld2; j2 += WAVE) {
@@ -275,6 +292,67 @@ __device__ __forceinline__ double virt_entry(double v, int i, int j, int np, con
     return v;
 }
 
+// revised form: entry (i, c) of B^-1 as it is after the pending pivots, given its stored value (no column swap: see LpView)
+__device__ __forceinline__ double virt_entry_b(double v, int i, int c, int np, const PivDesc *pd, const double *prow, const double *pcol, int ldt, int Mp1p)
+{
+    for (int s = 0; s < np; s++) {
+        const PivDesc d = pd[s];
+        if (i == d.r) v = -prow[(size_t)s * ldt + c] * d.p;
+        else v = fma(-pcol[(size_t)s * Mp1p + i], prow[(size_t)s * ldt + c], v);
+    }
+    return v;
+}
+// revised form: uvec = -K_N x_N of LP b (one workgroup per LP), and beta[M] = d . x_N.  which: nullptr = every LP of the batch,
+// else the work list of round `it` (only the LPs waiting for a refresh of beta are done).
+__global__ __launch_bounds__(NT) void k_rev_u(LpView L, BatchView Bv, int B, const int *which, int it)
+{
+    __shared__ double sv[NT / WAVE];
+    int b = blockIdx.x;
+    if (which) { if (b >= Bv.nwork[it]) return; b = Bv.work[b]; if (Bv.mode[b] != MODE_REFRESH) return; }
+    else if (b >= B) return;
+    const int slot = Bv.dst[b], M = L.M, N = L.N;
+    const int *nh = L.nh + (size_t)slot * N, *pos = L.pos + (size_t)slot * (M + N);
+    const double *xN = L.xN + (size_t)slot * L.ld;
+    double *xf = Bv.xfull + (size_t)b * N, *u = Bv.uvec + (size_t)b * L.ldt;
+    for (int j = threadIdx.x; j < N; j += NT) xf[j] = 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    const double *dc = Bv.dcur + (size_t)b * L.ld;
+    for (int j = threadIdx.x; j < N; j += NT) {
+        const int k = nh[j];
+        const double v = xN[j];
+        if (k >= M) xf[k - M] = v;
+        acc = fma(dc[j], v, acc);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L.ldt; i += NT) {
+        double ui = 0.0;
+        if (i < M) {
+            const int p = pos[i];
+            if (p < 0) ui = xN[-1 - p];                        // the auxiliary variable of row i is nonbasic: + e_i x_i
+            for (int t = L.rptr[i]; t < L.rptr[i + 1]; t++) ui = fma(-L.rval[t], xf[L.ridx[t]], ui);
+        }
+        u[i] = -ui;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < NT / WAVE; w++) t += sv[w]; L.beta[(size_t)slot * L.Mp1p + M] = t; }
+}
+// revised form: the reduced costs of every LP of the batch go to its slot (the tableau form has them in row M, which k_flush updates)
+__global__ void k_rev_store_d(LpView L, BatchView Bv, int B)
+{
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && j < L.ld) L.dsl[(size_t)Bv.dst[b] * L.ld + j] = Bv.dcur[(size_t)b * L.ld + j];
+}
+__global__ void k_rev_identity(LpView L, int slot, const double *cost)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < (size_t)L.M * L.ldt) { const int i = (int)(k / L.ldt), c = (int)(k % L.ldt); L.T[(size_t)slot * L.slotT + k] = i == c ? 1.0 : 0.0; }
+    if (k < (size_t)L.ld) L.dsl[(size_t)slot * L.ld + k] = k < (size_t)L.N ? cost[k + 1] : 0.0;
+}
+
 // EXT = the extended selection, compiled in when the LP has boxed variables (two finite, non-artificial bounds):
 //  * bound flipping ("long step") ratio test: the dual step passes the breakpoints of boxed candidates -- they switch to
 //    their other bound instead of entering the basis -- for as long as the leaving row stays infeasible.  Without it every
@@ -321,12 +399,91 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
     int *nstat = L.nstat + (size_t)slot * L.N, *pos = L.pos + (size_t)slot * (L.M + L.N);
     const int M = L.M, N = L.N, ld = L.ld;
     const PivDesc *pd = Bv.desc + (size_t)b * KP;
-    double *prow0 = Bv.prow + (size_t)b * KP * ld;
+    const int ldt = L.ldt;
+    double *prow0 = Bv.prow + (size_t)b * KP * ldt;
     double *pcol0 = Bv.pcol + (size_t)b * KP * L.Mp1p;
     double *drow = Bv.dcur + (size_t)b * ld;
     double *dwork = drow;                      // the reduced costs the dual ratio test works with
-    double *row = prow0 + (size_t)np * ld;     // the pivot row as it is after the pending pivots, where k_flush will read it
+    // the pivot row as it is after the pending pivots, where k_flush will read it (revised form: k_flush reads the row of B^-1, brow,
+    // from there, and the tableau row lives in a scratch vector of the LP)
+    double *row = L.rev ? Bv.trow + (size_t)b * ld : prow0 + (size_t)np * ld;
     double *pc = pcol0 + (size_t)np * L.Mp1p;  // the multipliers of the rows (primal selection: first the entering column itself)
+    // row r / column q of the tableau as it is after the pending pivots, by the whole workgroup (barriers inside)
+    auto fetch_row = [&](const int r) {
+        if (!L.rev) {
+            for (int j = tid; j < ld; j += NT) row[j] = j < N ? virt_entry(T0[(size_t)r * ld + j], r, j, np, pd, prow0, pcol0, ld, L.Mp1p) : 0.0;
+        } else {
+            double *brow = prow0 + (size_t)np * ldt;
+            for (int c = tid; c < ldt; c += NT) brow[c] = c < M ? ((L.probe & 4) ? T0[(size_t)r * ldt + c] : virt_entry_b(T0[(size_t)r * ldt + c], r, c, np, pd, prow0, pcol0, ldt, L.Mp1p)) : 0.0;
+            __syncthreads();
+            if (L.probe & 1) { for (int j = tid; j < ld; j += NT) row[j] = (j < N && nh[j] < M) ? -brow[nh[j]] : (j < N ? 1e-3 : 0.0); __syncthreads(); return; }
+            // one sparse dot product per nonbasic column.  The non-zeros of a column are fetched EIGHT at a time with independent loads
+            // (index, value, then the gathers from rho) and two columns are in flight per thread: entry after entry, each a chain of
+            // three dependent loads, cost 0.7 ms per selection on ex09 (37 000 columns, one workgroup) -- most of every pivot
+            constexpr int RU = 8;
+            auto dot8 = [&](int beg, int end) -> double {
+                double v = 0.0;
+                for (int t0 = beg; t0 < end; t0 += RU) {
+                    int ix[RU]; double va[RU], rh[RU];
+#pragma unroll
+                    for (int u = 0; u < RU; u++) { const bool in = t0 + u < end; ix[u] = in ? L.cidx[t0 + u] : 0; va[u] = in ? L.cval[t0 + u] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < RU; u++) rh[u] = brow[ix[u]];
+#pragma unroll
+                    for (int u = 0; u < RU; u++) v = fma(rh[u], va[u], v);
+                }
+                return v;
+            };
+            for (int j = tid; j < ld; j += 2 * NT) {
+                const int j2 = j + NT;
+                const int k1 = j < N ? nh[j] : -1, k2 = j2 < N ? nh[j2] : -1;
+                const int b1 = k1 >= M ? L.cptr[k1 - M] : 0, e1 = k1 >= M ? L.cptr[k1 - M + 1] : 0;
+                const int b2 = k2 >= M ? L.cptr[k2 - M] : 0, e2 = k2 >= M ? L.cptr[k2 - M + 1] : 0;
+                double v1 = (k1 >= 0 && k1 < M) ? -brow[k1] : 0.0, v2 = (k2 >= 0 && k2 < M) ? -brow[k2] : 0.0;
+                if (e1 - b1 <= RU && e2 - b2 <= RU) {             // (the usual case: both columns in one round of loads)
+                    int ix[2 * RU]; double va[2 * RU], rh[2 * RU];
+#pragma unroll
+                    for (int u = 0; u < RU; u++) {
+                        const bool i1 = b1 + u < e1, i2 = b2 + u < e2;
+                        ix[u] = i1 ? L.cidx[b1 + u] : 0; va[u] = i1 ? L.cval[b1 + u] : 0.0;
+                        ix[RU + u] = i2 ? L.cidx[b2 + u] : 0; va[RU + u] = i2 ? L.cval[b2 + u] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2 * RU; u++) rh[u] = brow[ix[u]];
+#pragma unroll
+                    for (int u = 0; u < RU; u++) { v1 = fma(rh[u], va[u], v1); v2 = fma(rh[RU + u], va[RU + u], v2); }
+                } else { v1 += dot8(b1, e1); v2 += dot8(b2, e2); }
+                row[j] = v1;
+                if (j2 < ld) row[j2] = v2;
+            }
+        }
+        __syncthreads();
+    };
+    auto fetch_col = [&](const int q) {
+        if (!L.rev) {
+            for (int i = tid; i < M; i += NT) pc[i] = virt_entry(T0[(size_t)i * ld + q], i, q, np, pd, prow0, pcol0, ld, L.Mp1p);
+        } else {
+            const int kq = nh[q];
+            if (L.probe & 2) { for (int i = tid; i < M; i += NT) pc[i] = i == 0 ? 1.0 : 1e-3; __syncthreads(); return; }
+            for (int i = tid; i < M; i += NT) {           // (B^-1 as stored) K_kq
+                const double *Bi = T0 + (size_t)i * ldt;
+                double v = 0.0;
+                if (kq < M) v = Bi[kq];
+                else for (int t = L.cptr[kq - M]; t < L.cptr[kq - M + 1]; t++) v = fma(-L.cval[t], Bi[L.cidx[t]], v);
+                pc[i] = v;
+            }
+            for (int sp = 0; sp < np; sp++) {              // ... through the pending pivots, in order
+                __syncthreads();
+                const PivDesc d = pd[sp];
+                const double vr = pc[d.r];
+                __syncthreads();
+                for (int i = tid; i < M; i += NT) pc[i] = i == d.r ? -d.p * vr : fma(-pcol0[(size_t)sp * L.Mp1p + i], vr, pc[i]);
+            }
+            __syncthreads();
+            for (int i = tid; i < M; i += NT) pc[i] = -pc[i];      // T[:, q] = -B^-1 K_kq
+        }
+        __syncthreads();
+    };
     int pf = 0;
     if constexpr (EXT) {
         pf = Bv.pflags[b];
@@ -382,8 +539,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         const int stq = nstat[q], kq = nh[q];
         const double dq = drow[q];
         const double dir = (stq == NS_U || (stq == NS_F && dq > 0.0)) ? -1.0 : 1.0;
-        for (int i = tid; i < M; i += NT) pc[i] = virt_entry(T0[(size_t)i * ld + q], i, q, np, pd, prow0, pcol0, ld, L.Mp1p);
-        __syncthreads();
+        fetch_col(q);
         double cmax = 0.0;
         for (int i = tid; i < M; i += NT) cmax = fmax(cmax, fabs(pc[i]));
         cmax = block_max(cmax, sv);
@@ -435,9 +591,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         }
         r = lv.i >> 1;
         below = !(lv.i & 1);                   // the leaving variable goes to its lower bound
-        for (int j = tid; j < ld; j += NT)
-            row[j] = j < N ? virt_entry(T0[(size_t)r * ld + j], r, j, np, pd, prow0, pcol0, ld, L.Mp1p) : 0.0;
-        __syncthreads();
+        fetch_row(r);
         have_col = true;
     } else {
     // ---- dual simplex step ----
@@ -509,9 +663,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
     r = best.i >> 1;
     below = best.i & 1;
     const double sgn = below ? 1.0 : -1.0;
-    for (int j = tid; j < ld; j += NT)
-        row[j] = j < N ? virt_entry(T0[(size_t)r * ld + j], r, j, np, pd, prow0, pcol0, ld, L.Mp1p) : 0.0;
-    __syncthreads();
+    fetch_row(r);
 
     // pass 0: row scale for the relative pivot tolerance
     double rmax = 0.0;
@@ -625,7 +777,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         // reads instead of a pass over the whole tableau, and the LP keeps selecting (up to KP pivots per pass as without
         // switches).  Many switches (a cold start walks hundreds of breakpoints): the pass with MODE_REFRESH as before.
         // beta is recomputed from the tableau before any status is reported (verified), so the update cannot end in a result.
-        if (nflip > 0 && nflip <= FLIP_INCR_MAX) {
+        if (nflip > 0 && nflip <= FLIP_INCR_MAX && !L.rev) {      // (revised form: a column of the tableau is a product, not a gather -- the refresh pass)
             __syncthreads();
             for (int i = tid; i <= M; i += NT) {
                 double acc = 0.0;
@@ -641,6 +793,8 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         }
     }
     }
+    bool col_ready = have_col;                                       // pc[] holds the entering column (primal steps fetch it first)
+    if (L.rev && !col_ready) { fetch_col(q); col_ready = true; }    // (the tableau form gathers its column in Phase D)
     // Phase C: the descriptor, the basis heads
     if (tid == 0) {
         int kb = bh[r], kn = nh[q];
@@ -684,7 +838,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
     // Phase D: the entering column as it is after the pending pivots -> multipliers of all rows, beta; the reduced-cost row
     for (int i = tid; i <= M; i += NT) {
         if (i == r) { pc[i] = 0.0; beta[i] = d.enter_val; continue; }
-        const double f = (i == M ? drow[q] : (have_col ? pc[i] : virt_entry(T0[(size_t)i * ld + q], i, q, np, pd, prow0, pcol0, ld, L.Mp1p))) * d.p;
+        const double f = (i == M ? drow[q] : (col_ready ? pc[i] : virt_entry(T0[(size_t)i * ld + q], i, q, np, pd, prow0, pcol0, ld, L.Mp1p))) * d.p;
         pc[i] = f;
         beta[i] = fma(-f, d.pbeta, beta[i]);
     }
@@ -757,7 +911,7 @@ __global__ __launch_bounds__(NT_BIG) void k_flush(LpView L, BatchView Bv, int it
     __shared__ PivDesc s_pd[KP];
     const int nitems = Bv.nwork[it] * tiles;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ld = L.ld, ld2 = ld >> 1;
+    const int ld = L.ldt, ld2 = ld >> 1;         // (row length of the slot matrix: the tableau, or B^-1 in the revised form)
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int b = Bv.work[item / tiles], tile = item % tiles;
         const int np = Bv.npend[b];
@@ -775,11 +929,11 @@ __global__ __launch_bounds__(NT_BIG) void k_flush(LpView L, BatchView Bv, int it
             if (threadIdx.x < np) s_pd[threadIdx.x] = Bv.desc[(size_t)b * KP + threadIdx.x];
         }
         __syncthreads();
-        const double2 *x2 = reinterpret_cast<const double2 *>(L.xN + (size_t)slot * ld);
+        const double2 *x2 = reinterpret_cast<const double2 *>(L.rev ? Bv.uvec + (size_t)b * ld : L.xN + (size_t)slot * ld);      // (rev: beta = B^-1 uvec, k_rev_u)
         const bool same = Tin == T;
         for (int rr = wave; rr < tr; rr += NT / WAVE) {
             const int i = tile * tr + rr;
-            if (i >= L.Mp1) break;
+            if (i >= L.mrows) break;
             double f[KP];
             bool isr[KP], any = false;
 #pragma unroll
@@ -798,7 +952,7 @@ __global__ __launch_bounds__(NT_BIG) void k_flush(LpView L, BatchView Bv, int it
                 for (int s = 0; s < KP; s++) {
                     if (s >= np) break;
                     const double2 pr = WIDE ? reinterpret_cast<const double2 *>(rowsg + (size_t)s * ld)[j2] : reinterpret_cast<const double2 *>(s_rows + (size_t)s * ld)[j2];
-                    const int q2 = s_pd[s].q >> 1, qodd = s_pd[s].q & 1;
+                    const int q2 = L.rev ? -1 : s_pd[s].q >> 1, qodd = s_pd[s].q & 1;       // (B^-1 has no column swap)
                     if (isr[s]) { const double p = s_pd[s].p; v.x = -pr.x * p; v.y = -pr.y * p; if (j2 == q2) { if (qodd) v.y = p; else v.x = p; } }
                     else { const double fs = f[s]; v.x = fma(-fs, pr.x, v.x); v.y = fma(-fs, pr.y, v.y); if (j2 == q2) { if (qodd) v.y = fs; else v.x = fs; } }
                 }
@@ -820,7 +974,7 @@ __global__ void k_list_unpivoted(BatchView Bv, int B, int slot_of_count)
 __global__ __launch_bounds__(NT) void k_copy_unpivoted(LpView L, BatchView Bv, int slot_of_count, int tiles)
 {
     const int nitems = Bv.nwork[slot_of_count] * tiles;
-    const int ld2 = L.ld >> 1;
+    const int ld2 = L.ldt >> 1;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int b = Bv.work[item / tiles], tile = item % tiles;
         const double2 *s = reinterpret_cast<const double2 *>(L.T + (size_t)Bv.src[b] * L.slotT);
@@ -840,7 +994,7 @@ __global__ void k_get(LpView L, const int *slots, int B, int first, int cnt, int
     int p = L.pos[(size_t)slot * (L.M + L.N) + k];
     double v;
     if (what == 0) v = p >= 0 ? L.beta[(size_t)slot * L.Mp1p + p] : L.xN[(size_t)slot * L.ld + (-1 - p)];
-    else v = p >= 0 ? 0.0 : L.T[(size_t)slot * L.slotT + (size_t)L.M * L.ld + (-1 - p)];
+    else v = p >= 0 ? 0.0 : (L.rev ? L.dsl[(size_t)slot * L.ld + (-1 - p)] : L.T[(size_t)slot * L.slotT + (size_t)L.M * L.ld + (-1 - p)]);
     out[idx] = v;
 }
 __global__ void k_get_obj(LpView L, const int *slots, int B, double c0, double *out)
@@ -871,7 +1025,11 @@ struct bslv_lpq {
     int slots = 0;
     double c0 = 0;
     hipStream_t stream = nullptr;
-    double *Tstd = nullptr;           // (M+1) x ld image of [A ; cost]
+    double *Tstd = nullptr;           // (M+1) x ld image of [A ; cost] (tableau form)
+    // revised form: A once as CSC and CSR, the cost vector, per-slot reduced costs, per-LP scratch
+    int *cptr_d = nullptr, *cidx_d = nullptr, *rptr_d = nullptr, *ridx_d = nullptr; double *cval_d = nullptr, *rval_d = nullptr, *cost_d = nullptr, *dsl_d = nullptr;
+    double *trow_d = nullptr, *uvec_d = nullptr, *xfull_d = nullptr;
+    long nnzA = 0;
     double *lb_d = nullptr, *ub_d = nullptr;
     unsigned char *art_d = nullptr;
     std::vector<double> cost;         // N+1
@@ -928,6 +1086,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     auto fr = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d); fr(h->work_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d);
+    fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
     if (h->status_h) { (void)hipHostFree(h->status_h); h->status_h = nullptr; }
     if (h->active_h) { (void)hipHostFree(h->active_h); h->active_h = nullptr; }
     h->Bcap = 0;
@@ -941,7 +1100,12 @@ static int ensure_batch(bslv_lpq *h, int B)
     size_t vc = (size_t)std::max(1, h->L.vcnt);
     HIP_TRY(malloc0(&h->vlo_d, cap * vc * sizeof(double)));
     HIP_TRY(malloc0(&h->vup_d, cap * vc * sizeof(double)));
-    HIP_TRY(malloc0(&h->prow_d, (size_t)cap * KP * h->L.ld * sizeof(double)));
+    HIP_TRY(malloc0(&h->prow_d, (size_t)cap * KP * h->L.ldt * sizeof(double)));
+    if (h->L.rev) {
+        HIP_TRY(malloc0(&h->trow_d, (size_t)cap * h->L.ld * sizeof(double)));
+        HIP_TRY(malloc0(&h->uvec_d, (size_t)cap * h->L.ldt * sizeof(double)));
+        HIP_TRY(malloc0(&h->xfull_d, (size_t)cap * h->L.N * sizeof(double)));
+    }
     HIP_TRY(malloc0(&h->desc_d, (size_t)cap * KP * sizeof(PivDesc)));
     HIP_TRY(malloc0(&h->pcol_d, (size_t)cap * KP * h->L.Mp1p * sizeof(double)));
     HIP_TRY(malloc0(&h->dcur_d, (size_t)cap * h->L.ld * sizeof(double)));
@@ -966,6 +1130,7 @@ static BatchView bview(bslv_lpq *h)
     v.desc = h->desc_d; v.prow = h->prow_d; v.pcol = h->pcol_d; v.dcur = h->dcur_d; v.npend = h->npend_d; v.flushed = h->flushed_d;
     v.work = h->work_d; v.nwork = h->nwork_d;
     v.dper = h->dper_d; v.pflags = h->pflags_d; v.stall = h->stall_d; v.xstat = h->xstat_d;
+    v.trow = h->trow_d; v.uvec = h->uvec_d; v.xfull = h->xfull_d;
     return v;
 }
 
@@ -1041,7 +1206,17 @@ static int raw_create(bslv_lpq **out, int M, int N, const double *A, const doubl
     L.vfirst = var_first; L.vcnt = var_cnt;
     L.maxit = 50 * (M + N) + 1000;
     L.bland_after = 4 * (M + N) + 200;
-    L.slotT = (size_t)L.Mp1 * L.ld;
+    // tableau or revised form?  The revised form pays a sparse product per tableau row / column it looks at and moves M x M instead of
+    // (M + 1) x N doubles per pass: for wide (N >= 2 M) and sparse (< 2 % non-zeros) problems of some size.  BSLV_LP_REV=0/1 forces it.
+    long nnz = 0;
+    for (size_t k = 0; k < (size_t)M * N; k++) nnz += A[k] != 0.0;
+    h->nnzA = nnz;
+    bool rev = N >= 2 * M && nnz * 50 < (long)M * N && (long)M * N >= (1L << 22);
+    if (const char *e = getenv("BSLV_LP_REV")) rev = atoi(e) != 0;
+    L.rev = rev ? 1 : 0;
+    L.ldt = rev ? (M + 15) / 16 * 16 : L.ld;
+    L.mrows = rev ? M : L.Mp1;
+    L.slotT = (size_t)L.mrows * L.ldt;
     h->slots = pool_slots;
     h->cost.assign(cost, cost + N + 1);
     h->c0 = cost[0];
@@ -1065,13 +1240,38 @@ static int raw_create(bslv_lpq **out, int M, int N, const double *A, const doubl
     TRYF(malloc0(&L.nh, (size_t)pool_slots * N * sizeof(int)));
     TRYF(malloc0(&L.nstat, (size_t)pool_slots * N * sizeof(int)));
     TRYF(malloc0(&L.pos, (size_t)pool_slots * (M + N) * sizeof(int)));
-    TRYF(malloc0(&h->Tstd, L.slotT * sizeof(double)));
+    if (!rev) TRYF(malloc0(&h->Tstd, L.slotT * sizeof(double)));
+    else {
+        TRYF(malloc0(&h->dsl_d, (size_t)pool_slots * L.ld * sizeof(double)));
+        TRYF(malloc0(&h->cost_d, (size_t)(N + 1) * sizeof(double)));
+        TRYF(malloc0(&h->cptr_d, (size_t)(N + 1) * sizeof(int)));
+        TRYF(malloc0(&h->rptr_d, (size_t)(M + 1) * sizeof(int)));
+        TRYF(malloc0(&h->cidx_d, (size_t)std::max(nnz, 1L) * sizeof(int)));
+        TRYF(malloc0(&h->ridx_d, (size_t)std::max(nnz, 1L) * sizeof(int)));
+        TRYF(malloc0(&h->cval_d, (size_t)std::max(nnz, 1L) * sizeof(double)));
+        TRYF(malloc0(&h->rval_d, (size_t)std::max(nnz, 1L) * sizeof(double)));
+    }
     TRYF(malloc0(&h->lb_d, (M + N) * sizeof(double)));
     TRYF(malloc0(&h->ub_d, (M + N) * sizeof(double)));
     TRYF(malloc0(&h->art_d, (M + N)));
 #undef TRYF
     L.lb = h->lb_d; L.ub = h->ub_d; L.art = h->art_d;
-    {
+    L.dsl = h->dsl_d; L.cptr = h->cptr_d; L.cidx = h->cidx_d; L.cval = h->cval_d; L.rptr = h->rptr_d; L.ridx = h->ridx_d; L.rval = h->rval_d;
+    if (rev) {
+        std::vector<int> cptr(N + 1, 0), rptr(M + 1, 0), cidx((size_t)nnz), ridx((size_t)nnz);
+        std::vector<double> cval((size_t)nnz), rval((size_t)nnz);
+        size_t t = 0;
+        for (int i = 0; i < M; i++) { rptr[i] = (int)t; for (int j = 0; j < N; j++) { const double a = A[(size_t)i * N + j]; if (a != 0.0) { ridx[t] = j; rval[t] = a; t++; cptr[j + 1]++; } } }
+        rptr[M] = (int)t;
+        for (int j = 0; j < N; j++) cptr[j + 1] += cptr[j];
+        std::vector<int> fill(cptr.begin(), cptr.end() - 1);
+        for (int i = 0; i < M; i++) for (int u = rptr[i]; u < rptr[i + 1]; u++) { const int j = ridx[u]; cidx[fill[j]] = i; cval[fill[j]] = rval[u]; fill[j]++; }
+        bool okc = hipMemcpy(h->cptr_d, cptr.data(), (N + 1) * sizeof(int), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(h->rptr_d, rptr.data(), (M + 1) * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+                   hipMemcpy(h->cost_d, cost, (N + 1) * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+        if (nnz) okc = okc && hipMemcpy(h->cidx_d, cidx.data(), nnz * sizeof(int), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(h->ridx_d, ridx.data(), nnz * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+                             hipMemcpy(h->cval_d, cval.data(), nnz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(h->rval_d, rval.data(), nnz * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+        if (!okc) { set_error("upload of A (CSC / CSR) failed"); return fail(BSLV_E_NODEVICE); }
+    } else {
         std::vector<double> img(L.slotT, 0.0);
         for (int i = 0; i < M; i++) memcpy(&img[(size_t)i * L.ld], A + (size_t)i * N, N * sizeof(double));
         for (int j = 0; j < N; j++) img[(size_t)M * L.ld + j] = cost[j + 1];
@@ -1082,9 +1282,9 @@ static int raw_create(bslv_lpq **out, int M, int N, const double *A, const doubl
     }
     if ((rc = upload_bounds(h, lb, ub))) return fail(rc);
     if ((rc = ensure_batch(h, 64))) return fail(rc);
-    h->force_ext = L.slotT * sizeof(double) >= ((size_t)1 << 30);
+    h->force_ext = L.slotT * sizeof(double) >= ((size_t)1 << 30) || (rev && (size_t)(M + 1) * L.ld * sizeof(double) >= ((size_t)1 << 30));     // (large problems are degenerate problems: no stalling at a millisecond per pivot)
     {   // k_flush stages KP pivot rows in LDS: wide problems (N > ~1300) need more than the default 64 KB
-        const size_t want = (size_t)KP * h->L.ld * sizeof(double);
+        const size_t want = (size_t)KP * h->L.ldt * sizeof(double);
         if (want > h->flush_lds_max) {
             if (want <= 144 * 1024 && hipFuncSetAttribute((const void *)k_flush<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) h->flush_lds_max = want;
             else (void)hipGetLastError();
@@ -1100,6 +1300,7 @@ void bslv_lpq_destroy(bslv_lpq *h)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
+    fr(h->cptr_d); fr(h->cidx_d); fr(h->rptr_d); fr(h->ridx_d); fr(h->cval_d); fr(h->rval_d); fr(h->cost_d); fr(h->dsl_d); fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d); fr(h->xstat_d); fr(h->cvals_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
@@ -1114,7 +1315,7 @@ size_t bslv_lpq_slot_bytes(const bslv_lpq *h)
 {
     if (!h) return 0;
     const LpView &L = h->L;
-    return (L.slotT + L.Mp1p + L.ld) * sizeof(double) + (size_t)(2 * (L.M + L.N) + L.N) * sizeof(int);
+    return (L.slotT + L.Mp1p + L.ld + (L.rev ? L.ld : 0)) * sizeof(double) + (size_t)(2 * (L.M + L.N) + L.N) * sizeof(int);
 }
 
 // bounds of the engine's model from the bounds of the model as given: the folded rows tighten their columns
@@ -1218,7 +1419,10 @@ int bslv_lpq_reset_slot(bslv_lpq *h, int slot)
 {
     if (!h || slot < 0 || slot >= h->slots) { set_error("bslv_lpq_reset_slot: bad slot %d", slot); return BSLV_E_ARG; }
     LpView &L = h->L;
-    HIP_TRY(hipMemcpyAsync(L.T + (size_t)slot * L.slotT, h->Tstd, L.slotT * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (L.rev) {
+        const size_t nk = std::max((size_t)L.M * L.ldt, (size_t)L.ld);
+        hipLaunchKernelGGL(k_rev_identity, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, h->stream, L, slot, (const double *)h->cost_d);
+    } else HIP_TRY(hipMemcpyAsync(L.T + (size_t)slot * L.slotT, h->Tstd, L.slotT * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     int n = std::max(std::max(L.M, L.N), std::max(L.ld, L.Mp1p));
     hipLaunchKernelGGL(k_std_heads, dim3((n + 255) / 256), dim3(256), 0, h->stream, L, slot);
     HIP_TRY(hipGetLastError());
@@ -1270,7 +1474,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     int rc;
     if ((rc = ensure_batch(h, B))) return rc;
     LpView &L = h->L;
-    const int wide = (size_t)KP * L.ld * sizeof(double) > h->flush_lds_max;      // pivot rows from global memory in k_flush
+    const int wide = (size_t)KP * L.ldt * sizeof(double) > h->flush_lds_max;      // pivot rows from global memory in k_flush
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = h->stream;
     HIP_TRY(hipMemcpyAsync(h->src_d, src, B * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1280,6 +1484,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         HIP_TRY(hipMemcpyAsync(h->vup_d, vup, (size_t)B * L.vcnt * sizeof(double), hipMemcpyHostToDevice, s));
     }
     L.objmode = cvals ? 1 : 0; L.cfirst = cfirst; L.ccnt = ccnt;
+    if (cvals && L.rev) { set_error("bslv_lpq_solve_batch_obj: not available in the revised form (BSLV_LP_REV=0 forces the tableau form)"); return BSLV_E_STATE; }
     if (cvals) {
         const size_t need = (size_t)B * ccnt;
         if (need > h->cvals_cap) { if (h->cvals_d) (void)hipFree(h->cvals_d); h->cvals_d = nullptr; HIP_TRY(malloc0s(&h->cvals_d, need * sizeof(double), s)); h->cvals_cap = need; }
@@ -1294,8 +1499,9 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     HIP_TRY(hipMemsetAsync(h->xstat_d, 0, 8 * sizeof(int), s));
     BatchView bv = bview(h);
     bv.cvals = h->cvals_d;
-    const int tiles = (L.Mp1 + TR - 1) / TR;
+    const int tiles = (L.mrows + TR - 1) / TR;
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(NT), 0, s, L, bv, B);
+    if (L.rev) hipLaunchKernelGGL(k_rev_u, dim3(B), dim3(NT), 0, s, L, bv, B, (const int *)nullptr, 0);      // beta = B^-1 uvec (k_init)
     if (L.objmode) {      // new objective: the tableau rows are copied up front (the reduced-cost row is rebuilt by k_prep, not streamed from the parent)
         const int cnt_slot = L.maxit + 41;
         hipLaunchKernelGGL(k_list_unpivoted, dim3((B + 255) / 256), dim3(256), 0, s, bv, B, -cnt_slot);
@@ -1303,7 +1509,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     }
     hipLaunchKernelGGL(k_init, dim3(tiles, B), dim3(NT), 0, s, L, bv, B);
     HIP_TRY(hipGetLastError());
-    const size_t lds = wide ? 0 : (size_t)KP * L.ld * sizeof(double);
+    const size_t lds = wide ? 0 : (size_t)KP * L.ldt * sizeof(double);
     // (160 KB of LDS per CU: three workgroups of NT threads need lds <= ~53 KB)
     const bool big_flush = getenv("BSLV_FLUSH_NT") ? atoi(getenv("BSLV_FLUSH_NT")) > NT : lds > 53 * 1024;
     // bound flipping ratio test only where a variable has two finite, non-artificial bounds
@@ -1334,7 +1540,9 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     HIP_TRY(hipMemcpyAsync(h->active_d, h->active_h, B * sizeof(int), hipMemcpyHostToDevice, s));
     size_t nev = 0;
     h->last_update_ms = 0;
-    while (running > 0 && it < L.maxit + 8) {
+    static const int max_rounds = getenv("BSLV_LP_MAXROUNDS") ? atoi(getenv("BSLV_LP_MAXROUNDS")) : 0;      // (timing experiments)
+    L.probe = getenv("BSLV_REV_PROBE") ? atoi(getenv("BSLV_REV_PROBE")) : 0;
+    while (running > 0 && it < L.maxit + 8 && !(max_rounds && it >= max_rounds)) {
         for (int c = 0; c < chunk; c++, it++) {
             for (int lev = 0; lev < KP; lev += sel_per_launch) {
                 if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(sel_nt), sel_lds, s, L, bv, h->active_d, running, cap2, sel_per_launch);
@@ -1352,11 +1560,12 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
             // few LPs left: smaller row tiles keep >= ~2k workgroups in flight
             int tr = running * tiles >= 2048 ? 32 : (running * tiles * 2 >= 2048 ? 16 : (running * tiles * 4 >= 2048 ? 8 : 4));      // (4: one row per wave -- a single LP of a few thousand rows)
             if (big_flush) {                                            // 16 waves per workgroup: at least one row per wave, more where the batch still fills the chip
-                const long rows = (long)running * L.Mp1;
+                const long rows = (long)running * L.mrows;
                 tr = rows >= 2048L * 128 ? 128 : rows >= 2048L * 64 ? 64 : rows >= 2048L * 32 ? 32 : 16;
             }
-            const int ntile = (L.Mp1 + tr - 1) / tr;
+            const int ntile = (L.mrows + tr - 1) / tr;
             const int fnt = big_flush ? NT_BIG : NT;
+            if (L.rev) hipLaunchKernelGGL(k_rev_u, dim3(running), dim3(NT), 0, s, L, bv, B, (const int *)h->work_d, it);      // (only the LPs that asked for a refresh of beta)
             if (wide) hipLaunchKernelGGL(k_flush<true>, dim3(std::min(running * ntile, h->upd_grid)), dim3(fnt), 0, s, L, bv, it, ntile, tr);
             else hipLaunchKernelGGL(k_flush<false>, dim3(std::min(running * ntile, h->upd_grid)), dim3(fnt), lds, s, L, bv, it, ntile, tr);
             if (h->profile) { HIP_TRY(hipEventRecord(h->evpool[nev].second, s)); nev++; }
@@ -1377,6 +1586,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         for (int k = 0; k < it; k++) passes += nw[k];
         h->last_passes = passes;
     }
+    if (L.rev) hipLaunchKernelGGL(k_rev_store_d, dim3((L.ld + 255) / 256, B), dim3(256), 0, s, L, bv, B);       // the reduced costs of every LP go to its slot
     {   // tableaux of the solves that made no pivot
         const int cnt_slot = L.maxit + 40;
         hipLaunchKernelGGL(k_list_unpivoted, dim3((B + 255) / 256), dim3(256), 0, s, bv, B, cnt_slot);
@@ -1400,6 +1610,10 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         h->last_update_ms = ms;
     }
     h->last_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    {
+        static const bool tm = getenv("BSLV_LP_TIMING") != nullptr;
+        if (tm) fprintf(stderr, "lp solve_batch: %s form %d x %d, B %d, %d lock-step rounds, %ld pivots, %ld passes, %.1f ms\n", L.rev ? "revised" : "tableau", L.M, L.N, B, it, h->last_pivots, h->last_passes, h->last_total_ms);
+    }
     return 0;
 }
 

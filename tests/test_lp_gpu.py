@@ -544,3 +544,61 @@ def test_a_row_on_a_column_with_per_lp_bounds_is_not_folded():
     assert np.all(st == 4), st
     np.testing.assert_allclose(eng.obj([1, 2]), [-1.0, -0.5], rtol=0, atol=1e-12)     # the row x0 <= 1 holds although LP 1 says x0 <= 5
     eng.close()
+
+
+def _sparse_covering(m, n, q, seed, per_col=4):
+    """covering VLP with a sparse A (per_col non-zeros per column, every row hit) and sparse objectives: the shape of ex07 / ex09"""
+    rng = np.random.default_rng(seed)
+    prob = synth.covering_vlp(m, n, q, seed)
+    A = np.zeros((m, n))
+    for j in range(n):
+        rows = rng.choice(m, size=per_col, replace=False)
+        A[rows, j] = rng.uniform(0.5, 1.5, size=per_col)
+    for i in range(m):
+        if not A[i].any():
+            A[i, rng.integers(n)] = 1.0
+    P = prob["P"] * (rng.random((q, n)) < 0.3)
+    P[:, 0] = prob["P"][:, 0]
+    prob = dict(prob, A=A, P=P)
+    return prob
+
+
+@pytest.mark.parametrize("m,n,q,seed,B", [(40, 300, 3, 5, 24), (90, 700, 4, 9, 48)])
+def test_revised_form_equals_the_tableau_form(monkeypatch, m, n, q, seed, B):
+    """SURVEY 8f rank 4 (the reference hands A to the solver as COO, bslv_lp.c:60-70): for wide sparse problems the engine keeps the
+    basis inverse per LP instead of the tableau and A once as CSC / CSR (BSLV_LP_REV=1 forces that form, 0 the tableau).  Same LPs
+    through both: statuses, optimal values (1e-9), primal values of y and of every x, duals w, the LP identities; cold start and a
+    warm-started batch; chains of warm starts (a child of a child) included."""
+    prob = _sparse_covering(m, n, q, seed)
+    model = P2Model(prob)
+    rng = np.random.default_rng(seed)
+    V = _random_V(model, prob, rng, B)
+    ub = model.ub_for(V)
+    res = {}
+    for rev in ("0", "1"):
+        monkeypatch.setenv("BSLV_LP_REV", rev)
+        eng = LpEngine.from_model(model, pool_slots=2 * B + 1)
+        eng.reset_slot(0)
+        st0, it0 = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+        assert st0[0] == 4, (rev, st0)
+        src = np.zeros(B, np.int32)
+        dst = np.arange(1, B + 1, dtype=np.int32)
+        st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+        assert np.all(st == 4), (rev, st)
+        # second generation: every LP again with a shifted right-hand side, from its own optimal slot into a new one
+        ub2 = model.ub_for(V * 1.07 + 0.01)
+        dst2 = np.arange(B + 1, 2 * B + 1, dtype=np.int32)
+        st2, it2 = eng.solve_batch(dst, dst2, np.full((B, model.r), -np.inf), ub2)
+        assert np.all(st2 == 4), (rev, st2)
+        res[rev] = dict(obj=eng.obj(dst).copy(), w=eng.dual(dst, model.w_first, q).copy(), y=eng.primal(dst, model.y_first, q).copy(), x=eng.primal(dst, model.M, n).copy(),
+                        obj2=eng.obj(dst2).copy(), w2=eng.dual(dst2, model.w_first, q).copy(), y2=eng.primal(dst2, model.y_first, q).copy(), it=int(it.sum()), it2=int(it2.sum()))
+        eng.close()
+    a, b = res["0"], res["1"]
+    assert b["it"] > 0 and b["it2"] > 0
+    np.testing.assert_allclose(b["obj"], a["obj"], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(b["obj2"], a["obj2"], rtol=RTOL, atol=1e-9)
+    _check_identities(model, V, b["obj"], b["w"], b["y"])
+    _check_identities(model, V * 1.07 + 0.01, b["obj2"], b["w2"], b["y2"])
+    # feasibility of the revised form's x at its optimum
+    assert np.all(b["x"] >= -1e-9) and np.all(b["x"] @ prob["A"].T >= 1 - 1e-8)
+    np.testing.assert_allclose(b["x"] @ prob["P"].T, b["y"], rtol=0, atol=1e-8)
