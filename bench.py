@@ -30,6 +30,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def bench_ex09_lp(args):
+    """--workload ex09-lp: the scalar LP of ex09 of the reference's suite (ex/ex09.vlp: 4608 x 36 939, 185 856 non-zeros, q = 3, ordering
+    cone with 6 generators -- SURVEY 8f rank 4, the problem the reference hands to GLPK as COO, bslv_lp.c:60-70) on the REVISED form
+    of the LP engine: basis inverse per LP (171 MB) instead of the tableau (1.36 GB), A once as CSC / CSR.  One step = a batch of
+    B P2(v) solves warm-started from one solved LP (B different right-hand sides); value = LPs / s over the K timed steps, the roofline
+    is the tableau-pass kernel on B^-1 (k_flush: 16 M ldt bytes per (LP, pass)).  One GPU."""
+    import numpy as np
+    import torch
+    from bensolve_amd.synth import read_vlp
+    from bensolve_amd.lp import P2Model, LpEngine
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(0)
+    steps = args.steps or 5
+    warm = 1 if args.warmup is None else args.warmup
+    B = args.batch or 32
+    prob = read_vlp(os.path.join(ROOT, "tests", "golden", "ex", "ex09.vlp"))
+    model = P2Model(prob)
+    os.environ.setdefault("BSLV_LP_REV", "1")          # (this workload IS the revised form; BSLV_LP_REV=0 python bench.py --workload ex09-lp rates the tableau form on the same LPs)
+    eng = LpEngine.from_model(model, pool_slots=B + 1)
+    dims = dict(M=model.M, N=model.N)
+    eng.reset_slot(0)
+    v0 = np.full((1, prob["q"]), 1e3)
+    t0 = time.perf_counter()
+    st, it = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), model.ub_for(v0)[:1])
+    cold = dict(status=int(st[0]), pivots=int(it[0]), secs=round(time.perf_counter() - t0, 2), **{k: eng.last_stats()[k] for k in ("passes", "lockstep_iters")})
+    print("bench: ex09 cold LP done: %s" % cold, file=sys.stderr, flush=True)
+    if st[0] != 4:
+        raise SystemExit("ex09-lp: the cold solve failed: status %d" % st[0])
+    rng = np.random.default_rng(9)
+    src = np.zeros(B, np.int32)
+    dst = np.arange(1, B + 1, dtype=np.int32)
+
+    bad = [0]
+
+    def one_step():
+        V = v0 * rng.uniform(0.75, 0.99, size=(B, 1))          # (points on the ray through v0: moderately far from the LP the batch starts from)
+        stv, itv = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), model.ub_for(V))
+        bad[0] += int((stv != 4).sum())        # (revised form: an LP whose inverse drifted comes back UNDEFINED for the caller's retry)
+        return int(itv.sum()), eng.last_stats()
+    for _ in range(warm):
+        one_step()
+    eng.set_profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    piv = passes = rounds = 0
+    upd_ms = 0.0
+    for _ in range(steps):
+        p, ls = one_step()
+        piv += p; passes += ls["passes"]; rounds += ls["lockstep_iters"]; upd_ms += ls["update_ms"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.set_profile(False)
+    rev = int(eng.lib.bslv_lpq_is_revised(eng.h))
+    eng.close()
+    ldt = (model.M + 15) // 16 * 16
+    alg = 16.0 * model.M * ldt if rev else 16.0 * (model.M + 1) * ((model.N + 15) // 16 * 16)
+    achieved = passes * alg / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
+    out = {"metric": "scalar LPs/sec (P2(v) of ex/ex09.vlp: %d x %d, 185856 non-zeros, q=3), batches of %d warm-started LPs" % (model.M, model.N, B),
+           "value": round(steps * B / dt, 2), "unit": "LPs/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt * 1e3 / steps, 2), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "ex/ex09.vlp of the reference's suite (tests/golden/ex), right-hand sides synthetic",
+           "config": {"workload": "ex09-lp", "lp_rows_cols": [dims["M"], dims["N"]], "form": "revised (basis inverse per LP, A as CSC/CSR)" if rev else "tableau", "batch": B,
+                      "slot_bytes": 8 * model.M * ldt if rev else 8 * (model.M + 1) * model.N},
+           "pivots_per_lp": round(piv / max(steps * B, 1), 1), "passes": passes, "lockstep_rounds": rounds, "cold_start": cold, "lps_not_optimal": bad[0],
+           "roofline": {"bound": "hbm", "kernel": "k_flush on B^-1 (pending pivots applied in one pass)", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                        "traffic": None, "launches": rounds, "avg_launch_us": round(upd_ms * 1e3 / max(rounds, 1), 1), "alg_bytes_per_pass": alg,
+                        "note": "the pass is NOT what bounds this workload: the selection (k_select, one workgroup per LP: sparse row / column products and passes over 37 000 columns) is -- profiles/r04_ex09_lp_kernel_stats.csv"},
+           "cpu_baseline": {"value": None, "unit": "LPs/s", "cores": 1, "kind": "port", "sample": "none: oracle/lp_dense.c needs a dense 4618 x 36943 tableau per LP and minutes per cold solve -- not a bounded sample"}}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,6 +121,8 @@ def main():
     ap.add_argument("--no-pair", action="store_true", help="skip the S-small whole-run GPU/CPU pair of cpu_baseline")
     ap.add_argument("--cpu-lps", type=int, default=0, help="LPs of the CPU sample (default by workload)")
     args = ap.parse_args()
+    if args.workload == "ex09-lp":
+        return bench_ex09_lp(args)
 
     import numpy as np
     import torch

@@ -86,6 +86,7 @@ struct LpView {
     // and a pivot updates B^-1 by the SAME row operations it applies to the tableau -- row r := -rho p, row i -= f_i rho -- so the
     // delayed update, k_flush and its roofline carry over; only the tableau's column swap (entry q of every row) has no counterpart.
     // ex09: 171 MB per slot instead of 1.36 GB.  rev == 0: ldt = ld, mrows = M + 1 and everything is as before.
+    int rho_off;                // rev: byte offset of the LDS copy of rho (row of B^-1 the tableau row is built from) in k_select's dynamic LDS, or -1 (does not fit: gathers from global memory)
     int rev, ldt, mrows, probe;  // probe: BSLV_REV_PROBE, timing experiments only (parts of the revised selection skipped: results are WRONG)
     double *dsl;                // rev: [slots][ld] reduced costs of each slot (the tableau form keeps them as row M of T)
     const int *cptr, *cidx; const double *cval;   // rev: CSC of A
@@ -113,6 +114,7 @@ struct BatchView {
     double *trow;           // [B][ld]   the tableau row of the selection at hand (prow then holds rows of B^-1: [B][KP][ldt])
     double *uvec;           // [B][ldt]  -K_N x_N: beta = B^-1 uvec (k_rev_u; k_init and the refresh pass of k_flush multiply by it)
     double *xfull;          // [B][N]    scratch of k_rev_u: values of the nonbasic structurals by column
+    unsigned long long *dbg; // BSLV_REV_PROBE & 8: 100 MHz clock ticks per phase of the dual selection of LP 0 (timing experiments)
 };
 
 __device__ __forceinline__ double LO(const LpView &L, const BatchView &Bv, int b, int k)
@@ -413,9 +415,16 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         if (!L.rev) {
             for (int j = tid; j < ld; j += NT) row[j] = j < N ? virt_entry(T0[(size_t)r * ld + j], r, j, np, pd, prow0, pcol0, ld, L.Mp1p) : 0.0;
         } else {
-            double *brow = prow0 + (size_t)np * ldt;
-            for (int c = tid; c < ldt; c += NT) brow[c] = c < M ? ((L.probe & 4) ? T0[(size_t)r * ldt + c] : virt_entry_b(T0[(size_t)r * ldt + c], r, c, np, pd, prow0, pcol0, ldt, L.Mp1p)) : 0.0;
+            double *brow_g = prow0 + (size_t)np * ldt;
+            // rho also goes to LDS when it fits (ex09: 37 KB): the sparse products below gather from it ~200 000 times per selection
+            double *srho = L.rho_off >= 0 ? reinterpret_cast<double *>(dyn_sel + L.rho_off) : nullptr;
+            for (int c = tid; c < ldt; c += NT) {
+                const double v = c < M ? ((L.probe & 4) ? T0[(size_t)r * ldt + c] : virt_entry_b(T0[(size_t)r * ldt + c], r, c, np, pd, prow0, pcol0, ldt, L.Mp1p)) : 0.0;
+                brow_g[c] = v;
+                if (srho) srho[c] = v;
+            }
             __syncthreads();
+            const double *brow = srho ? srho : brow_g;
             if (L.probe & 1) { for (int j = tid; j < ld; j += NT) row[j] = (j < N && nh[j] < M) ? -brow[nh[j]] : (j < N ? 1e-3 : 0.0); __syncthreads(); return; }
             // one sparse dot product per nonbasic column.  The non-zeros of a column are fetched EIGHT at a time with independent loads
             // (index, value, then the gathers from rho) and two columns are in flight per thread: entry after entry, each a chain of
@@ -465,12 +474,21 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         } else {
             const int kq = nh[q];
             if (L.probe & 2) { for (int i = tid; i < M; i += NT) pc[i] = i == 0 ? 1.0 : 1e-3; __syncthreads(); return; }
-            for (int i = tid; i < M; i += NT) {           // (B^-1 as stored) K_kq
-                const double *Bi = T0 + (size_t)i * ldt;
-                double v = 0.0;
-                if (kq < M) v = Bi[kq];
-                else for (int t = L.cptr[kq - M]; t < L.cptr[kq - M + 1]; t++) v = fma(-L.cval[t], Bi[L.cidx[t]], v);
-                pc[i] = v;
+            const int cb = kq >= M ? L.cptr[kq - M] : 0, ce = kq >= M ? L.cptr[kq - M + 1] : 0;
+            for (int i0 = tid; i0 < M; i0 += 2 * NT) {    // (B^-1 as stored) K_kq: two rows per thread, the gathers of eight non-zeros of each in flight together
+                const int i1 = i0 + NT;
+                const double *B0 = T0 + (size_t)i0 * ldt, *B1 = T0 + (size_t)(i1 < M ? i1 : i0) * ldt;
+                double v0 = 0.0, v1 = 0.0;
+                if (kq < M) { v0 = B0[kq]; v1 = B1[kq]; }
+                else for (int t0 = cb; t0 < ce; t0 += 8) {
+                    double g0[8], g1[8], cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const bool in = t0 + u < ce; const int c = in ? L.cidx[t0 + u] : 0; cv[u] = in ? L.cval[t0 + u] : 0.0; g0[u] = B0[c]; g1[u] = B1[c]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { v0 = fma(-cv[u], g0[u], v0); v1 = fma(-cv[u], g1[u], v1); }
+                }
+                pc[i0] = v0;
+                if (i1 < M) pc[i1] = v1;
             }
             for (int sp = 0; sp < np; sp++) {              // ... through the pending pivots, in order
                 __syncthreads();
@@ -595,6 +613,8 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         have_col = true;
     } else {
     // ---- dual simplex step ----
+    unsigned long long tk = (L.probe & 8) ? wall_clock64() : 0ull;
+#define SEL_PHASE(k) do { if ((L.probe & 8) && b == 0) { __syncthreads(); if (tid == 0) { const unsigned long long tn = wall_clock64(); Bv.dbg[k] += tn - tk; tk = tn; } } } while (0)
     // Phase A: leaving row = largest bound violation; id = 2*i + (below ? 1 : 0)
     ValIdx best{0.0, -1};
     for (int i = tid; i < M; i += NT) {
@@ -663,7 +683,9 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
     r = best.i >> 1;
     below = best.i & 1;
     const double sgn = below ? 1.0 : -1.0;
+    SEL_PHASE(0);
     fetch_row(r);
+    SEL_PHASE(1);
 
     // pass 0: row scale for the relative pivot tolerance
     double rmax = 0.0;
@@ -731,17 +753,32 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         }
     }
     // pass 1: Harris bound on the dual step
+    SEL_PHASE(2);
+    // (both passes fetch FOUR columns per thread and iteration with all loads issued first: on wide problems -- ex09: 37 000 columns,
+    // 36 per thread -- a column after the other, its reduced cost loaded behind two branches, was a chain of ~100 memory latencies;
+    // min and the (value, index) arg-max do not depend on the order)
+    constexpr int PU = 4;
     double th = INFINITY;
-    for (int j = tid; j < N; j += NT) {
-        int st = nstat[j];
-        if (st == NS_S) continue;
-        if (EXT && sflag[j]) continue;
-        double a = sgn * row[j];
-        if (fabs(a) < ptol) continue;
-        if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
-            th = fmin(th, (fabs(dwork[j]) + (bland ? 0.0 : TOL_DJ)) / fabs(a));
+    for (int j0 = tid; j0 < N; j0 += PU * NT) {
+        int stv[PU]; double av[PU], dv[PU]; bool skip[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int j = j0 + u * NT;
+            const bool in = j < N;
+            stv[u] = in ? nstat[j] : NS_S; av[u] = in ? sgn * row[j] : 0.0; dv[u] = in ? dwork[j] : 0.0;
+            skip[u] = !in || (EXT && sflag[in ? j : 0]);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int st = stv[u];
+            const double a = av[u];
+            if (skip[u] || st == NS_S || fabs(a) < ptol) continue;
+            if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
+                th = fmin(th, (fabs(dv[u]) + (bland ? 0.0 : TOL_DJ)) / fabs(a));
+        }
     }
     th = block_min(th, sv);
+    SEL_PHASE(3);
     if (isinf(th)) {                      // no entering candidate: primal infeasible ...
         if (!(Bv.verified[b] & 1)) {      // ... unless the violation is rounding debris in beta: recompute it first
             if (tid == 0) Bv.mode[b] = MODE_REFRESH;
@@ -752,16 +789,26 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
     }
     // pass 2: largest |pivot| within the bound
     ValIdx piv{0.0, -1};
-    for (int j = tid; j < N; j += NT) {
-        int st = nstat[j];
-        if (st == NS_S) continue;
-        if (EXT && sflag[j]) continue;
-        double a = sgn * row[j];
-        if (fabs(a) < ptol) continue;
-        if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
-            if (fabs(dwork[j]) / fabs(a) <= th) piv = better_max(piv, ValIdx{bland ? (double)(L.M + L.N - nh[j]) : fabs(a), j});
+    for (int j0 = tid; j0 < N; j0 += PU * NT) {
+        int stv[PU]; double av[PU], dv[PU]; bool skip[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int j = j0 + u * NT;
+            const bool in = j < N;
+            stv[u] = in ? nstat[j] : NS_S; av[u] = in ? sgn * row[j] : 0.0; dv[u] = in ? dwork[j] : 0.0;
+            skip[u] = !in || (EXT && sflag[in ? j : 0]);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int st = stv[u], j = j0 + u * NT;
+            const double a = av[u];
+            if (skip[u] || st == NS_S || fabs(a) < ptol) continue;
+            if ((a > 0 && (st == NS_L || st == NS_F)) || (a < 0 && (st == NS_U || st == NS_F)))
+                if (fabs(dv[u]) / fabs(a) <= th) piv = better_max(piv, ValIdx{bland ? (double)(L.M + L.N - nh[j]) : fabs(a), j});
+        }
     }
     piv = block_argmax(piv, sv, si);
+    SEL_PHASE(4);
     q = piv.i;
     if constexpr (EXT) {
         // the switches: other bound, other status.  beta no longer matches xN: this pivot is applied at once and beta
@@ -794,7 +841,9 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
     }
     }
     bool col_ready = have_col;                                       // pc[] holds the entering column (primal steps fetch it first)
+    unsigned long long tk2 = (L.probe & 8) ? wall_clock64() : 0ull;
     if (L.rev && !col_ready) { fetch_col(q); col_ready = true; }    // (the tableau form gathers its column in Phase D)
+    if ((L.probe & 8) && b == 0) { __syncthreads(); if (tid == 0) { const unsigned long long tn = wall_clock64(); Bv.dbg[5] += tn - tk2; tk2 = tn; } }
     // Phase C: the descriptor, the basis heads
     if (tid == 0) {
         int kb = bh[r], kn = nh[q];
@@ -802,6 +851,14 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         double target = below ? lo : up;
         double trq = row[q];
         double br = beta[r];
+        // revised form: the pivot element comes out of TWO products -- rho K_q (the row) and the column B^-1 K_q -- which agree as long as
+        // B^-1 is accurate.  Nothing refactorises it; when the two drift apart the LP is given up as UNDEFINED and the caller's retry
+        // (bslv_lp.c:222-227: from the standard basis, an exact identity) takes over instead of a solve on a corrupted inverse
+        if (L.rev && !(fabs(trq - pc[r]) <= 1e-8 * (1.0 + fabs(trq)))) {
+            Bv.status[b] = BSLV_LP_UNDEFINED; Bv.mode[b] = MODE_NONE;
+            if (L.trace == b) printf("lp %d it %d: pivot element from the row %.17g, from the column %.17g: B^-1 has drifted\n", b, Bv.iters[b], trq, pc[r]);
+            s_d.r = -1;
+        } else {
         PivDesc d;
         d.r = r; d.q = q; d.p = 1.0 / trq;
         d.pbeta = br - target;
@@ -832,9 +889,11 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         Bv.mode[b] = (nflip > 0 && !incr) ? MODE_REFRESH : MODE_PIVOT;
         Bv.verified[b] &= 2;
         Bv.iters[b] += 1;
+        }
     }
     __syncthreads();
     const PivDesc d = s_d;
+    if (d.r < 0) return true;                      // (given up: see above)
     // Phase D: the entering column as it is after the pending pivots -> multipliers of all rows, beta; the reduced-cost row
     for (int i = tid; i <= M; i += NT) {
         if (i == r) { pc[i] = 0.0; beta[i] = d.enter_val; continue; }
@@ -856,6 +915,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         }
     }
     if (tid == 0) Bv.npend[b] = np + 1;
+    if ((L.probe & 8) && b == 0) { __syncthreads(); if (tid == 0) { Bv.dbg[6] += wall_clock64() - tk2; Bv.dbg[7] += 1; } }
     return true;
 }
 // One launch selects up to nsel pivots per LP, one after the other, by the same workgroup: the KP selections between two passes
@@ -1028,6 +1088,7 @@ struct bslv_lpq {
     double *Tstd = nullptr;           // (M+1) x ld image of [A ; cost] (tableau form)
     // revised form: A once as CSC and CSR, the cost vector, per-slot reduced costs, per-LP scratch
     int *cptr_d = nullptr, *cidx_d = nullptr, *rptr_d = nullptr, *ridx_d = nullptr; double *cval_d = nullptr, *rval_d = nullptr, *cost_d = nullptr, *dsl_d = nullptr;
+    unsigned long long *dbg_d = nullptr;
     double *trow_d = nullptr, *uvec_d = nullptr, *xfull_d = nullptr;
     long nnzA = 0;
     double *lb_d = nullptr, *ub_d = nullptr;
@@ -1043,6 +1104,7 @@ struct bslv_lpq {
     long last_ext[5] = {0, 0, 0, 0, 0};
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
     size_t select_lds_max = 64 * 1024; // dynamic LDS of k_select<true> (candidate sort of the bound flipping ratio test)
+    size_t select0_lds_max = 64 * 1024; // ... of k_select<false> (revised form: rho)
     bool has_boxed = false;            // some variable outside the per-LP range has two finite, non-artificial bounds
     bool force_ext = false;            // extended selection (perturbation, primal clean-up) also without a boxed variable: bslv_lpq_set_extended,
                                        // and by itself for tableaux of 1 GiB and more (every pivot costs a millisecond there: no stalling)
@@ -1113,6 +1175,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     HIP_TRY(malloc0(&h->pflags_d, cap * sizeof(int)));
     HIP_TRY(malloc0(&h->stall_d, cap * sizeof(int)));
     if (!h->xstat_d) HIP_TRY(malloc0(&h->xstat_d, 8 * sizeof(int)));
+    if (!h->dbg_d) HIP_TRY(malloc0(&h->dbg_d, 16 * sizeof(unsigned long long)));
     HIP_TRY(malloc0(&h->npend_d, cap * sizeof(int)));
     HIP_TRY(malloc0(&h->flushed_d, cap * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->status_h, cap * sizeof(int)));
@@ -1130,7 +1193,7 @@ static BatchView bview(bslv_lpq *h)
     v.desc = h->desc_d; v.prow = h->prow_d; v.pcol = h->pcol_d; v.dcur = h->dcur_d; v.npend = h->npend_d; v.flushed = h->flushed_d;
     v.work = h->work_d; v.nwork = h->nwork_d;
     v.dper = h->dper_d; v.pflags = h->pflags_d; v.stall = h->stall_d; v.xstat = h->xstat_d;
-    v.trow = h->trow_d; v.uvec = h->uvec_d; v.xfull = h->xfull_d;
+    v.trow = h->trow_d; v.uvec = h->uvec_d; v.xfull = h->xfull_d; v.dbg = h->dbg_d;
     return v;
 }
 
@@ -1207,11 +1270,13 @@ static int raw_create(bslv_lpq **out, int M, int N, const double *A, const doubl
     L.maxit = 50 * (M + N) + 1000;
     L.bland_after = 4 * (M + N) + 200;
     // tableau or revised form?  The revised form pays a sparse product per tableau row / column it looks at and moves M x M instead of
-    // (M + 1) x N doubles per pass: for wide (N >= 2 M) and sparse (< 2 % non-zeros) problems of some size.  BSLV_LP_REV=0/1 forces it.
+    // (M + 1) x N doubles per pass: for wide (N >= 2 M) and sparse (< 2 % non-zeros) problems.  BSLV_LP_REV=0/1 forces it.
     long nnz = 0;
     for (size_t k = 0; k < (size_t)M * N; k++) nnz += A[k] != 0.0;
     h->nnzA = nnz;
-    bool rev = N >= 2 * M && nnz * 50 < (long)M * N && (long)M * N >= (1L << 22);
+    // (by itself only where tableaux are out of reach -- 4 GiB and more each; ex09's 1.36 GB tableaux still fit 140 times into 288 GB and
+    // the tableau form is the faster one for its one-LP-at-a-time phases and needs no refactorisation: DESIGN.md section 5)
+    bool rev = N >= 2 * M && nnz * 50 < (long)M * N && (size_t)(M + 1) * (size_t)L.ld * sizeof(double) >= ((size_t)4 << 30);
     if (const char *e = getenv("BSLV_LP_REV")) rev = atoi(e) != 0;
     L.rev = rev ? 1 : 0;
     L.ldt = rev ? (M + 15) / 16 * 16 : L.ld;
@@ -1300,7 +1365,7 @@ void bslv_lpq_destroy(bslv_lpq *h)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
-    fr(h->cptr_d); fr(h->cidx_d); fr(h->rptr_d); fr(h->ridx_d); fr(h->cval_d); fr(h->rval_d); fr(h->cost_d); fr(h->dsl_d); fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
+    fr(h->dbg_d); fr(h->cptr_d); fr(h->cidx_d); fr(h->rptr_d); fr(h->ridx_d); fr(h->cval_d); fr(h->rval_d); fr(h->cost_d); fr(h->dsl_d); fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d); fr(h->xstat_d); fr(h->cvals_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
@@ -1352,6 +1417,7 @@ int bslv_lpq_set_bounds(bslv_lpq *h, const double *lb, const double *ub)
     return upload_bounds(h, lo.data(), up.data());
 }
 int bslv_lpq_rows_folded(const bslv_lpq *h) { return h ? h->ps.nfold : 0; }
+int bslv_lpq_is_revised(const bslv_lpq *h) { return h ? h->L.rev : 0; }
 
 int bslv_lpq_create(bslv_lpq **out, int M, int N, const double *A, const double *lb, const double *ub,
                     const double *cost, int var_first, int var_cnt, int pool_slots)
@@ -1526,6 +1592,20 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         else bfrt = false;
     }
     if (L.objmode && !bfrt) { set_error("bslv_lpq_solve_batch_obj: rows too long for the extended selection (N=%d)", L.N); return BSLV_E_CAPACITY; }
+    // revised form: rho (a row of B^-1) in LDS behind the selection's own arrays, when there is room
+    size_t sel_lds_launch = bfrt ? sel_lds : 0;
+    L.rho_off = -1;
+    if (L.rev) {
+        const size_t off = bfrt ? (sel_lds + 15) / 16 * 16 : 0, want = off + (size_t)L.ldt * sizeof(double);
+        size_t &lim = bfrt ? h->select_lds_max : h->select0_lds_max;
+        bool ok = want <= lim;
+        if (!ok && want <= 144 * 1024) {
+            ok = (bfrt ? hipFuncSetAttribute((const void *)k_select<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want)
+                       : hipFuncSetAttribute((const void *)k_select<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want)) == hipSuccess;
+            if (ok) lim = want; else (void)hipGetLastError();
+        }
+        if (ok) { L.rho_off = (int)off; sel_lds_launch = want; }
+    }
     L.trace = getenv("BSLV_LP_TRACE") ? atoi(getenv("BSLV_LP_TRACE")) : -1;
     L.stall_limit = getenv("BSLV_STALL_LIMIT") ? atoi(getenv("BSLV_STALL_LIMIT")) : STALL_LIMIT;
     L.pert_scale = getenv("BSLV_PERT_SCALE") ? atof(getenv("BSLV_PERT_SCALE")) : 1.0;
@@ -1545,8 +1625,8 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     while (running > 0 && it < L.maxit + 8 && !(max_rounds && it >= max_rounds)) {
         for (int c = 0; c < chunk; c++, it++) {
             for (int lev = 0; lev < KP; lev += sel_per_launch) {
-                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(sel_nt), sel_lds, s, L, bv, h->active_d, running, cap2, sel_per_launch);
-                else hipLaunchKernelGGL(k_select<false>, dim3(running), dim3(sel_nt), 0, s, L, bv, h->active_d, running, 0, sel_per_launch);
+                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(sel_nt), sel_lds_launch, s, L, bv, h->active_d, running, cap2, sel_per_launch);
+                else hipLaunchKernelGGL(k_select<false>, dim3(running), dim3(sel_nt), sel_lds_launch, s, L, bv, h->active_d, running, 0, sel_per_launch);
             }
             hipLaunchKernelGGL(k_list_pending, dim3((running + 255) / 256), dim3(256), 0, s, bv, h->active_d, running, it);
             if (h->profile) {
@@ -1610,6 +1690,14 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         h->last_update_ms = ms;
     }
     h->last_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (L.probe & 8) {
+        unsigned long long dg[16];
+        HIP_TRY(hipMemcpy(dg, h->dbg_d, sizeof dg, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(h->dbg_d, 0, sizeof dg));
+        const double n = (double)std::max<unsigned long long>(dg[7], 1) * 100.0;       // ticks of 10 ns -> us per selection
+        fprintf(stderr, "lp select phases (LP 0, %llu selections, us each): leaving row %.1f | tableau row %.1f | row scale + candidates %.1f | Harris pass %.1f | pivot choice %.1f | column %.1f | descriptor + vector updates %.1f\n",
+                dg[7], dg[0] / n, dg[1] / n, dg[2] / n, dg[3] / n, dg[4] / n, dg[5] / n, dg[6] / n);
+    }
     {
         static const bool tm = getenv("BSLV_LP_TIMING") != nullptr;
         if (tm) fprintf(stderr, "lp solve_batch: %s form %d x %d, B %d, %d lock-step rounds, %ld pivots, %ld passes, %.1f ms\n", L.rev ? "revised" : "tableau", L.M, L.N, B, it, h->last_pivots, h->last_passes, h->last_total_ms);

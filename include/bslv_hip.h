@@ -72,6 +72,14 @@ void bslv_lpq_destroy(bslv_lpq *h);
  * interface stays an index of the model AS GIVEN (GLPK's, bslv_lp.c:60-70): get_primal of a folded row returns a_ij x_j, get_dual
  * the column's reduced cost over a_ij when the column sits on the bound that row gave it.  BSLV_NO_PRESOLVE=1 switches it off. */
 int  bslv_lpq_rows_folded(const bslv_lpq *h);
+/* REVISED FORM (the reference hands A to its solver as COO, bslv_lp.c:60-70 -> glp_load_matrix): for wide sparse
+ * problems the engine can keep the BASIS INVERSE of every LP (M x M) instead of its tableau ((M+1) x N) and A once, as CSC and CSR,
+ * for the whole pool; tableau rows and columns are sparse products, the delayed update and its pass kernel run on B^-1 (ex09 of the
+ * reference's suite: 171 MB per LP instead of 1.36 GB).  Same interface, same slots and warm starts; bslv_lpq_solve_batch_obj is not
+ * available in this form, and nothing refactorises B^-1: an LP whose inverse has drifted (the pivot element from its row and from its
+ * column disagree) comes back BSLV_LP_UNDEFINED for the caller's retry from the standard basis (bslv_lp.c:222-227).  Chosen by itself
+ * for N >= 2 M, < 2 % non-zeros and tableaux of 4 GiB and more; BSLV_LP_REV=0 / 1 forces the form.  Returns 1 in the revised form. */
+int  bslv_lpq_is_revised(const bslv_lpq *h);
 int  bslv_lpq_pool_slots(const bslv_lpq *h);
 size_t bslv_lpq_slot_bytes(const bslv_lpq *h);
 /* replace the shared bounds (lp_set_rows / lp_set_cols, bslv_lp.c:112-134) */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # timing experiment (results are WRONG with a probe bit set): which part of the revised selection costs what on one cold ex09 LP
 export TMPDIR=/tmp
-for p in 0 1 2 4 7; do
+for p in ${PROBES:-0 1 2 4 7}; do
   BSLV_REV_PROBE=$p BSLV_LP_MAXROUNDS=300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_p$p -o p -- python3 scripts/probe/ex09_lp_stats.py > gpurun_out/rev_probe_$p.log 2>&1
   ks=$(find gpurun_out/prof_p$p -name "*kernel_stats.csv" | head -1)
   python3 - "$ks" $p <<PY
