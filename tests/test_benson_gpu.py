@@ -498,3 +498,41 @@ def test_families_that_hold_only_directions_do_not_end_the_run_early(batch):
     assert np.all(d["ps"][d["pu"].astype(bool)] == 1)         # every live element was processed
     eng.close()
     ph.assert_benson_results_agree(got, exp)
+
+
+def test_different_batch_rules_give_outer_approximations_of_the_same_image():
+    """The default batch rule (whole families, shallowest parent cut first) ends on a DIFFERENT eps-approximation than the
+    reference-like rule (newest vertices first) wherever the image has features below eps -- fewer facets, fewer LPs.
+    Both must be outer approximations of the same upper image within eps: every vertex of either polyhedron satisfies every cut of the
+    other up to ~eps (Benson accepts a vertex whose LP value is <= eps, bslv_algs.c:1063; each cut is a supporting hyperplane of the
+    image).  Also with the rounds' shared on-plane elements off: three polyhedra, pairwise.  A covering problem at q = 4."""
+    import os
+    prob = synth.covering_vlp(120, 60, 4, 11)
+    eps, batch = 1e-7, 512
+    res = {}
+    for name, pol, share in (("families", 6, 1), ("newest first", 1, 1), ("families, one owner per element", 6, 0)):
+        eng = BensonEngine(prob, eps=eps, pool_slots=4 * batch + 64)
+        eng.set_policy(pol)
+        eng.poly_call("debug_set", 15, share)
+        assert eng.start() == 0
+        eng.run(batch)
+        d = eng.poly_dump()
+        tot = eng.totals()
+        eng.close()
+        assert np.all(d["ps"][d["pu"].astype(bool)] == 1)
+        X = d["X"][d["pu"].astype(bool) & (d["pi"] == 0)]
+        Y = d["Y"][d["du"].astype(bool) & (d["di"] == 0)]
+        res[name] = (X, Y, tot)
+    names = list(res)
+    scale = max(1.0, max(np.abs(res[n][0]).max() for n in names))
+    for a in names:
+        for b in names:
+            if a == b:
+                continue
+            X, Y = res[a][0], res[b][1]
+            w = np.hstack([Y[:, :-1], 1 - Y[:, :-1].sum(axis=1, keepdims=True)])        # lowerV2upperH with c = (1, ..., 1): normal (y*_1..q-1, 1 - sum), rhs y*_q
+            worst = 0.0
+            for c0 in range(0, len(w), 20000):
+                worst = min(worst, float((X @ w[c0:c0 + 20000].T - Y[c0:c0 + 20000, -1][None, :]).min()))
+            assert worst >= -5 * eps * scale, "vertices of '%s' violate a cut of '%s' by %.3e (eps %.0e)" % (a, b, -worst, eps)
+    print("batch rules: " + ", ".join("%s: %d vertices, %d facets, %d LPs" % (n, len(res[n][0]), len(res[n][1]), res[n][2]["lps"]) for n in names))
