@@ -20,6 +20,7 @@ struct Shadow {
     Side P, D;
     std::vector<btstrg> sltn_sent;         // primal sltn bits already handed to the engine
     bool apex_checked = false, lists_fresh = false;
+    int nv_seen = 0;                       // primal slots whose coordinates the mirror already holds (refresh)
 };
 std::map<const void *, Shadow *> g_by_ptr;       // poly_args*, &args->primal, &args->dual  ->  shadow
 
@@ -70,7 +71,12 @@ void refresh(Shadow *S)
     grow_side(&a->primal, S->P, (size_t)std::max(nv, 1));        // (never empty: the bit sets and arrays exist from the start)
     grow_side(&a->dual, S->D, (size_t)std::max(nf, 1));
     std::vector<unsigned char> u(std::max(nv, nf) + 1), id(std::max(nv, nf) + 1), sl(nv + 1);
-    if (nv > 0 && bslv_poly_get_primal(S->eng, u.data(), id.data(), sl.data(), a->primal.data)) die("bslv_poly_get_primal");
+    // flags of every slot (a byte each), coordinates only of the slots that are new since the last call: a slot's coordinates never
+    // change (the whole array again on every poly__add_vrtx made the reference's driver quadratic in the number of slots)
+    if (nv > 0 && bslv_poly_get_primal(S->eng, u.data(), id.data(), sl.data(), nullptr)) die("bslv_poly_get_primal");
+    if (nv < S->nv_seen) S->nv_seen = 0;
+    if (nv > S->nv_seen && bslv_poly_get_primal_range(S->eng, S->nv_seen, nv - S->nv_seen, a->primal.data + (size_t)S->nv_seen * d)) die("bslv_poly_get_primal_range");
+    S->nv_seen = nv;
     for (int i = 0; i < nv; i++) { setbit(a->primal.used, i, u[i]); setbit(a->primal.ideal, i, id[i]); setbit(a->primal.sltn, i, sl[i]); }
     a->primal.cnt = (size_t)nv;
     S->sltn_sent.assign(a->primal.sltn, a->primal.sltn + nv / BT + 1);

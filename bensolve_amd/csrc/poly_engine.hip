@@ -1298,13 +1298,10 @@ __global__ __launch_bounds__(PB) void k_fm_fill(const unsigned long long *bits, 
     const int w = (int)(t / nm), m = (int)(t % nm);
     while (x) { const int b = __ffsll((long long)x) - 1; x &= x - 1; list[atomicAdd(&cur[w * 64 + b], 1)] = m; }
 }
-__global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum,
-                                                         const int *fm_cnt, const int *fm_off, const int *fm_list /* NULL: scan all elements */,
-                                                         int *nzlist /* NULL | blocks with an adjacent pair */, int *nzcount)
+// the pair test of one virtual pair block (row pb.i, columns pb.j0 + threadIdx.x) by the calling workgroup: is my pair adjacent?
+__device__ __forceinline__ bool pair_block_test(int d, const unsigned long long *bits, int nm, int W, const PairBlk pb,
+                                                const int *fm_cnt, const int *fm_off, const int *fm_list /* NULL: scan all elements */, unsigned long long *s_m)
 {
-    __shared__ Tri lds[16];
-    extern __shared__ unsigned long long s_m[];      // W words of row i, then 4 x W words (one M per wave)
-    const PairBlk pb = pair_block(nm, blockIdx.x);
     for (int w = threadIdx.x; w < W; w += PB) s_m[w] = bits[(size_t)w * nm + pb.i];
     __syncthreads();
     const int j = pb.j0 + threadIdx.x;
@@ -1359,6 +1356,16 @@ __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned lo
         __builtin_amdgcn_wave_barrier();
         if (lane == src) adj = !found;
     }
+    return adj;
+}
+__global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned long long *bits, int nm, int W, unsigned char *pflag, Tri *bsum,
+                                                         const int *fm_cnt, const int *fm_off, const int *fm_list /* NULL: scan all elements */,
+                                                         int *nzlist /* NULL | blocks with an adjacent pair */, int *nzcount)
+{
+    __shared__ Tri lds[16];
+    extern __shared__ unsigned long long s_m[];      // W words of row i, then 4 x W words (one M per wave)
+    const PairBlk pb = pair_block(nm, blockIdx.x);
+    const bool adj = pair_block_test(d, bits, nm, W, pb, fm_cnt, fm_off, fm_list, s_m);
     Tri t{adj ? 1 : 0, 0, 0};
     pflag[(size_t)blockIdx.x * PB + threadIdx.x] = adj ? 1 : 0;
     Tri tot;
@@ -1366,6 +1373,29 @@ __global__ __launch_bounds__(PB) void k_pair_flags_bits(int d, const unsigned lo
     if (threadIdx.x == 0) {
         bsum[blockIdx.x] = tot;
         if (nzlist && tot.a > 0) nzlist[atomicAdd(nzcount, 1)] = blockIdx.x;
+    }
+}
+// Emission WITHOUT a flag per pair (facets of several 10^5 elements: a flag byte per pair was 163 GB at 571 084 elements, the stop of
+// S-degenerate at q = 10): the pair blocks that hold an adjacent pair are known (nzlist, a few per element) and so is where each
+// block's pairs go (bpre: the scanned block sums of the flags pass); the listed blocks are simply tested AGAIN and write their pairs.
+__global__ __launch_bounds__(PB) void k_pair_retest_emit(int d, const unsigned long long *bits, int nm, int W, const int *fm_cnt, const int *fm_off, const int *fm_list,
+                                                          const int *members, const int *nzlist, const int *nzcount, const Tri *bpre, int2 *E, int ebase, int *EP)
+{
+    __shared__ Tri lds[16];
+    extern __shared__ unsigned long long s_m[];
+    const int n = *nzcount;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int blk = nzlist[k];
+        const PairBlk pb = pair_block(nm, blk);
+        const bool adj = pair_block_test(d, bits, nm, W, pb, fm_cnt, fm_off, fm_list, s_m);
+        Tri t{adj ? 1 : 0, 0, 0};
+        Tri tot;
+        const Tri ex = block_exscan(t, &tot, lds);
+        if (adj) {
+            E[ebase + bpre[blk].a + ex.a] = int2{members[pb.i], members[pb.j0 + threadIdx.x]};
+            if (EP) EP[ebase + bpre[blk].a + ex.a] = -1;
+        }
+        __syncthreads();          // (s_m is reused by the next listed block)
     }
 }
 
@@ -1444,7 +1474,7 @@ __global__ __launch_bounds__(PB) void k_pair_flags_tiled(int d, const unsigned l
             if (lane == src) adj = !found;
         }
         const long long vb = GL - pair_G(L1 - i) + c;           // virtual block (row i, chunk c), as pair_block enumerates them
-        pflag[(size_t)vb * PB + threadIdx.x] = adj ? 1 : 0;
+        if (pflag) pflag[(size_t)vb * PB + threadIdx.x] = adj ? 1 : 0;       // (nullptr: the listed blocks are tested again at emission, k_pair_retest_emit)
         const int cnt = __syncthreads_count(adj);
         if (threadIdx.x == 0) {
             bsum[vb] = Tri{cnt, 0, 0};
@@ -2739,6 +2769,16 @@ __global__ __launch_bounds__(PB) void k_dpair_flags(PolyView P, DualView D, int 
 }
 
 
+// which facet ranks have a live element on them (the reference clears dual.used when a facet's vertex list empties, bslv_poly.c:686-705):
+// one wave per live element walks its incidence list
+__global__ __launch_bounds__(PB) void k_live_ranks(PolyView P, int nv, unsigned char *live)
+{
+    const int i = blockIdx.x * (PB / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= nv || !(P.flag[i] & F_USED)) return;
+    const int *L = P.pool + P.inc_off[i];
+    const int n = P.inc_len[i];
+    for (int j = lane; j < n; j += WAVE) live[L[j]] = 1;
+}
 // measurement helper: overwrite the first nv element slots with synthetic live points (splitmix-like hash)
 __global__ void k_bench_fill(PolyView P, int nv, unsigned long long seed)
 {
@@ -2832,6 +2872,7 @@ struct bslv_poly {
     Tri *bsum2 = nullptr; size_t bsum2cap = 0;
     int *fm_cnt = nullptr, *fm_list = nullptr; size_t fmcap = 0, fmlistcap = 0; int fm_min = 4096; long n_fm = 0; bool member_lists = true;
     // multi-GPU: pair space of large facets dealt to the ranks (k2_multi).  Below ~3e4 elements the two all-gathers cost more than the pair tests
+    bool k2_noflags = getenv("BSLV_K2_NOFLAGS") != nullptr; long n_noflag_prunes = 0;     // large-facet prunes emit by testing the listed pair blocks again instead of keeping a flag per pair
     int shard_min = 32768; long n_sharded = 0; int2 *shard_e = nullptr; size_t shardcap = 0;
     int *nzlist = nullptr; size_t nzcap = 0;         // pair blocks with an adjacent pair (+ their count behind the list)      // facet-major member lists of a large new facet (k_fm_*)       // chunk totals of the two-level scan (k_scan_chunks)
     Tri *totals = nullptr;            // device, 4 entries
@@ -3066,7 +3107,12 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     int rc;
     const long long nbp = pair_G(nm - 1);
     if (nbp > 0x7FFFFFF0ll) { set_error("new facet has too many elements (%d) for one pair launch", nm); return BSLV_E_CAPACITY; }
-    if ((size_t)nbp * PB > h->pflagcap) { size_t nc = std::max((size_t)nbp * PB, h->pflagcap * 2); if ((rc = grow(&h->pflag, 0, nc, s))) return rc; h->pflagcap = nc; }
+    // one flag byte per pair between the test and the ordered emission -- unless that array is out of reach (k_pair_retest_emit below)
+    auto ensure_pflag = [&]() -> int {
+        if ((size_t)nbp * PB > h->pflagcap) { size_t nc = std::max((size_t)nbp * PB, h->pflagcap * 2); if ((rc = grow(&h->pflag, 0, nc, s))) return rc; h->pflagcap = nc; }
+        return 0;
+    };
+    bool noflags = false;
     if ((rc = ensure_bsum(h, (int)nbp + 1))) return rc;
     // local incidence bit matrix: at most one local id per list entry of the members
     const int nranks = (int)h->facet_of_rank.size();
@@ -3085,6 +3131,10 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
         const int ngroups = (nm - 1 + PTI - 1) / PTI;
         const bool tiled = nm >= h->fm_min && h->d > 1 && lds_tiled <= 48 * 1024;      // (more than 65535 row groups: several launches, below)
         const bool fm = tiled && h->member_lists && len_ub <= (1ll << 30);
+        // large facets: no flag array at all from 4 GiB of flags on (bslv_poly_debug_set key 16 / BSLV_K2_NOFLAGS=1: always, for the tests);
+        // not when the pair space is dealt to the ranks (each rank's share of the flags is a fraction)
+        noflags = tiled && !(bslv_dist_world() > 1 && nm >= h->shard_min) && (h->k2_noflags || (size_t)nbp * PB >= ((size_t)4 << 30));
+        if (!noflags && (rc = ensure_pflag())) return rc;
         if (tiled) {
             if ((size_t)nbp > h->nzcap) { size_t nc = std::max((size_t)nbp, h->nzcap * 2); if (h->nzlist) (void)hipFree(h->nzlist); h->nzlist = nullptr; HIP_TRY(malloc0s(&h->nzlist, (nc + 1) * sizeof(int), s)); h->nzcap = nc; }
             HIP_TRY(hipMemsetAsync(h->nzlist + h->nzcap, 0, sizeof(int), s));
@@ -3119,7 +3169,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
                 h->n_sharded++;
             }
             for (int ga = g0; ga < g1; ga += 65535)          // (gridDim.y holds 65535 row groups: facets of more than 65535 * PTI elements take several launches)
-                hipLaunchKernelGGL(k_pair_flags_tiled, dim3((unsigned)((nm - 1 + PB - 1) / PB), (unsigned)std::min(65535, g1 - ga)), dim3(PB), lds_tiled, s, h->d, h->bits, nm, W, h->pflag, h->bsum,
+                hipLaunchKernelGGL(k_pair_flags_tiled, dim3((unsigned)((nm - 1 + PB - 1) / PB), (unsigned)std::min(65535, g1 - ga)), dim3(PB), lds_tiled, s, h->d, h->bits, nm, W, noflags ? (unsigned char *)nullptr : h->pflag, h->bsum,
                                    fm ? (const int *)h->fm_cnt : (const int *)nullptr, fm ? (const int *)(h->fm_cnt + W * 64) : (const int *)nullptr, fm ? (const int *)h->fm_list : (const int *)nullptr,
                                    h->nzlist, h->nzlist + h->nzcap, ga);
         }
@@ -3131,6 +3181,7 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
         }
         used_list = tiled;
     } else {    // enormous local facet sets: sorted-list version
+        if ((rc = ensure_pflag())) return rc;
         if ((long long)nbp * PB >= (1ll << 32)) { set_error("new facet has too many elements (%d) for the one-dimensional pair launch", nm); return BSLV_E_CAPACITY; }
         hipLaunchKernelGGL(k_pair_flags, dim3((unsigned)nbp), dim3(PB), 0, s, h->P, h->members, nm, (const PairBlk *)nullptr, h->pflag, h->bsum);
     }
@@ -3191,7 +3242,14 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     if (tp.a > 0) {
         if ((long long)h->ne + tp.a > 0x3FFFFF00ll) { set_error("polyhedron too large: more than 2^30 edges"); return BSLV_E_CAPACITY; }
         if ((rc = ensure_ecap(h, h->ne + tp.a))) return rc;
-        if (used_list)
+        if (noflags) {
+            const int Wn = (int)((std::min<long long>(len_ub, (long long)h->facet_of_rank.size()) + 63) / 64);
+            const bool fmn = h->member_lists && len_ub <= (1ll << 30);
+            hipLaunchKernelGGL(k_pair_retest_emit, dim3(4096), dim3(PB), (size_t)Wn * 5 * sizeof(unsigned long long), s, h->d, (const unsigned long long *)h->bits, nm, Wn,
+                               fmn ? (const int *)h->fm_cnt : (const int *)nullptr, fmn ? (const int *)(h->fm_cnt + Wn * 64) : (const int *)nullptr, fmn ? (const int *)h->fm_list : (const int *)nullptr,
+                               (const int *)h->members, (const int *)h->nzlist, (const int *)(h->nzlist + h->nzcap), (const Tri *)h->bsum, h->E[h->ecur], h->ne, h->EP[h->ecur]);
+            h->n_noflag_prunes++;
+        } else if (used_list)
             hipLaunchKernelGGL(k_pair_emit_list, dim3(4096), dim3(PB), 0, s, h->members, nm, (const int *)h->nzlist, (const int *)(h->nzlist + h->nzcap), (const unsigned char *)h->pflag,
                                (const Tri *)h->bsum, h->E[h->ecur], h->ne, h->EP[h->ecur]);
         else
@@ -4151,6 +4209,7 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 10: h->shard_min = (int)std::max(2L, value); return 0;           /* multi-GPU: facets from this size on have their pair space dealt to the ranks */
     case 13: h->r2_fuse = (int)std::min(2L, std::max(0L, value)); return 0;                           /* one launch for a round's prunes + classification + pair emission (1) / three (0) */
     case 12: h->r2_spec = value != 0; return 0;                           /* rounds queued one ahead of the host (1) / mailbox read before every round (0) */
+    case 16: h->k2_noflags = value != 0; return 0;                        /* multi-kernel prune of large facets without a flag byte per pair (forced; by itself from 4 GiB of flags on) */
     case 15: h->r2_share = value != 0; return 0;                          /* rounds: cuts may share on-plane elements (1) / every element belongs to one cut of a round (0) */
     case 11: h->r2_mis = value != 0; return 0;                            /* rounds: maximal independent set from the conflict matrix (1) / local minima of one order (0) */
     case 9: g_k1_mfma = value != 0; return 0;                            /* incidence kernel K1 on the matrix pipe from 16 halfspaces on (1) or the scalar kernel (0, default); process-wide */
@@ -4161,6 +4220,7 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     }
 }
 long bslv_poly_sharded_prunes(const bslv_poly *h) { return h ? h->n_sharded : 0; }
+long bslv_poly_noflag_prunes(const bslv_poly *h) { return h ? h->n_noflag_prunes : 0; }      // large-facet prunes that emitted by testing the listed pair blocks again (no flag byte per pair)
 long bslv_poly_rounds2_late_left(const bslv_poly *h) { return h ? h->r2_late_left : 0; }
 long bslv_poly_rounds2_torn_reads(const bslv_poly *h) { return h ? h->r2_torn_reads + h->mail_torn_reads : 0; }      // (both kinds of mailbox)
 
@@ -4299,6 +4359,20 @@ long bslv_poly_pair_tests(const bslv_poly *h) { return h ? h->pair_tests : 0; }
 long bslv_poly_new_vertices(const bslv_poly *h) { return h ? h->new_vertices : 0; }
 
 // slot-indexed dumps (host buffers sized by the counts above)
+// coordinates of the element slots first .. first + count - 1 only (row-major count x dim): what a caller that mirrors the polyhedron
+// needs after a cut -- the coordinates of a slot never change, only new slots appear (poly_compat.hip)
+int bslv_poly_get_primal_range(bslv_poly *h, int first, int count, double *coords)
+{
+    if (!h || first < 0 || count < 0 || first + count > h->nv || (count && !coords)) { set_error("bslv_poly_get_primal_range: bad argument"); return BSLV_E_ARG; }
+    if (count == 0) return 0;
+    const int d = h->d;
+    std::vector<double> col(count);
+    for (int k = 0; k < d; k++) {
+        HIP_TRY(hipMemcpy(col.data(), h->P.X + (size_t)k * h->P.cap + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; i++) coords[(size_t)i * d + k] = col[i];
+    }
+    return 0;
+}
 int bslv_poly_get_primal(bslv_poly *h, unsigned char *used, unsigned char *ideal, unsigned char *sltn, double *coords)
 {
     if (!h) return BSLV_E_ARG;
@@ -4373,12 +4447,21 @@ int bslv_poly_get_dual(bslv_poly *h, unsigned char *used, unsigned char *ideal, 
     const int nf = h->nf;
     std::vector<unsigned char> live(nf, 0);
     if (h->initialised) {
-        std::vector<unsigned char> fl; std::vector<unsigned> off; std::vector<int> len, pool;
-        int rc = fetch_inc(h, fl, off, len, pool);
-        if (rc) return rc;
-        for (int i = 0; i < h->nv; i++) {
-            if (!(fl[i] & F_USED)) continue;
-            for (int j = 0; j < len[i]; j++) { int f = h->facet_of_rank[pool[off[i] + j]]; if (h->fapplied[f]) live[f] = 1; }
+        // liveness of every facet rank on the device (one byte per rank comes back, not the incidence pool)
+        int rc;
+        if ((rc = settle_k2(h))) return rc;
+        const int nr = (int)h->facet_of_rank.size();
+        if (nr > 0) {
+            unsigned char *live_d = nullptr;
+            HIP_TRY(malloc0s(&live_d, (size_t)nr, h->stream));
+            HIP_TRY(hipMemsetAsync(live_d, 0, (size_t)nr, h->stream));
+            if (h->nv > 0) hipLaunchKernelGGL(k_live_ranks, dim3((h->nv + PB / WAVE - 1) / (PB / WAVE)), dim3(PB), 0, h->stream, h->P, h->nv, live_d);
+            std::vector<unsigned char> lr((size_t)nr);
+            hipError_t e = hipMemcpyAsync(lr.data(), live_d, (size_t)nr, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            (void)hipFree(live_d);
+            HIP_TRY(e);
+            for (int rk = 0; rk < nr; rk++) if (lr[rk]) { const int f = h->facet_of_rank[rk]; if (h->fapplied[f]) live[f] = 1; }
         }
     } else
         for (int f = 0; f < nf; f++) live[f] = h->fapplied[f];

@@ -158,6 +158,7 @@ int  bslv_poly_path_stats(const bslv_poly *h, long out[6]);
  * key 10 changes the threshold): every rank tests a contiguous share of the rows, the adjacent pairs found are all-gathered and
  * appended in rank order, which is the order a single GPU writes them in */
 long bslv_poly_sharded_prunes(const bslv_poly *h);
+long bslv_poly_noflag_prunes(const bslv_poly *h);      /* large-facet prunes that kept no flag byte per pair (k_pair_retest_emit) */
 /* cuts that were still untouched when a chunk's rounds ended on "no cut alive" and were handed to the one-cut pipeline instead
  * (0 in every run but one of round 2's test runs; kept as a counter so that it cannot hide) */
 long bslv_poly_rounds2_late_left(const bslv_poly *h);
@@ -213,6 +214,9 @@ long bslv_poly_pair_tests(const bslv_poly *h);
 long bslv_poly_new_vertices(const bslv_poly *h);
 int  bslv_poly_get_primal(bslv_poly *h, unsigned char *used, unsigned char *ideal, unsigned char *sltn, double *coords);
 int  bslv_poly_get_dual(bslv_poly *h, unsigned char *used, unsigned char *ideal, double *coords);
+/* coordinates of the primal slots first .. first+count-1 only (count x dim, row-major): the coordinates of a slot never change, so
+ * a caller that mirrors `polytope` (poly_compat.hip, bslv_poly.h:55-69) fetches only what a cut added */
+int  bslv_poly_get_primal_range(bslv_poly *h, int first, int count, double *coords);
 int  bslv_poly_get_edges(bslv_poly *h, int *ab);
 int  bslv_poly_get_inc(bslv_poly *h, int *pairs);
 int  bslv_poly_get_dual_edges(bslv_poly *h, int *ab);

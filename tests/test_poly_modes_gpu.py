@@ -4,6 +4,7 @@ capacity short) must all build the SAME polyhedron, slot by slot.  The modes are
 test hooks (environment variables read by bslv_poly_create) and compared bit for bit with the CPU oracle
 (oracle/poly_dd.c restates bslv_poly.c:104-330) and with each other."""
 import os
+import ctypes
 import numpy as np
 import pytest
 
@@ -337,11 +338,15 @@ def test_large_facets_member_list_prune_equals_full_scan():
             h.update(np.ascontiguousarray(d[key]).tobytes())
         return h.hexdigest(), int(d["pu"].sum()), len(d["E"])
 
-    for name, lists, steps in (("member lists", 1, 5), ("full scan", 0, 5), ("untiled", 1, 4)):
+    for name, lists, steps in (("member lists", 1, 5), ("full scan", 0, 5), ("untiled", 1, 4), ("no flag array", 1, 5)):
         eng = BensonEngine(prob, eps=1e-7, pool_slots=4 * 64 + 64)
         eng.poly_call("debug_set", 5, lists)
         if name == "untiled":
             eng.poly_call("debug_set", 4, 1 << 30)            # no facet is 'large': one-dimensional k_pair_flags_bits for every fallback prune
+        if name == "no flag array":
+            # (round 4) the pairs are written by testing the listed pair blocks AGAIN instead of from a flag byte per pair: what facets of
+            # several 10^5 elements need (163 GB of flags at 571 084 elements); forced here for every large facet
+            eng.poly_call("debug_set", 16, 1)
         assert eng.start() == 0
         d4 = None
         for it in range(steps):
@@ -353,6 +358,9 @@ def test_large_facets_member_list_prune_equals_full_scan():
                 d4 = digest(eng.poly_dump())
         d = eng.poly_dump()
         paths = eng.poly_call("path_stats")
+        eng.lib.bslv_poly_noflag_prunes.restype = ctypes.c_long
+        eng.lib.bslv_poly_noflag_prunes.argtypes = [ctypes.c_void_p]
+        paths["noflag"] = int(eng.lib.bslv_poly_noflag_prunes(eng._poly_h))
         eng.close()
         out[name] = (digest(d), d4, paths)
         if name == "member lists":
@@ -361,5 +369,6 @@ def test_large_facets_member_list_prune_equals_full_scan():
             assert bad == 0, "%d of %d sampled pairs of the largest facet (%d elements) disagree with the host edge test" % (bad, n, fsize)
     assert out["member lists"][2]["member_list_prunes"] > 20 and out["full scan"][2]["member_list_prunes"] == 0 and out["untiled"][2]["member_list_prunes"] == 0, out
     assert out["member lists"][0][1] > 500000       # (live elements after five steps: 596 861 with the batches taken newest first, round 3)
-    assert out["member lists"][0] == out["full scan"][0], out
+    assert out["member lists"][0] == out["full scan"][0] == out["no flag array"][0], out
+    assert out["no flag array"][2]["noflag"] > 20 and out["member lists"][2]["noflag"] == 0, out
     assert out["member lists"][1] == out["full scan"][1] == out["untiled"][1], out       # after four steps, all three kernels
