@@ -169,7 +169,7 @@ def main():
                                  "set BSLV_BENCH_ALLOW_FALLBACK=1 to measure the torch.distributed fallback instead" % (world, transport))
 
     if args.steps is None:
-        args.steps = 3 if args.workload == "S-degenerate" else 20     # (the rate moves with the window: waves of redundant LPs -- 5-step windows gave 62 k .. 108 k LPs/s on S-mid; 20 steps average over them)
+        args.steps = 20     # (the rate moves with the window: waves of redundant LPs -- 5-step windows gave 62 k .. 108 k LPs/s on S-mid; 20 steps average over them.  S-degenerate: as far as its polyhedron lets it, see `stopped`)
     if args.warmup is None:
         args.warmup = 0 if args.workload == "S-degenerate" else 4
     defaults = {"S-small": 2048, "S-mid": 2048, "S-degenerate": 64}
@@ -254,6 +254,12 @@ def main():
     r2s0 = eng.poly_call("rounds2_stats")
     nv0 = eng.poly_call("counts")["new_vertices"]
     pt0 = eng.poly_call("counts")["pair_tests"]
+    def lazy_stats():
+        o = (ctypes.c_long * 3)()
+        eng.lib.bslv_lpq_lazy_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        eng.lib.bslv_lpq_lazy_stats(eng._lp_h, o)
+        return [int(o[0]), int(o[1]), o[2] / 1000.0]
+    lz0 = lazy_stats()
     lps = cuts = pivots = lockstep = redundant = confirmed = passes = 0
     upd_ms = 0.0
     lp_ms = 0.0
@@ -261,8 +267,20 @@ def main():
     step_t = []                          # host clock at the end of every timed step (for the spread of the rate over windows)
     step_lps = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s = one_step()
+    stopped = None                       # S-degenerate at q = 10 outgrows the engine's 32-bit block / edge indices after a number of steps: the line then rates the steps that completed
+    steps_asked = args.steps
+    for k_step in range(args.steps):
+        try:
+            s = one_step()
+        except Exception as e:
+            if args.workload != "S-degenerate" or world > 1 or k_step == 0:
+                raise
+            stopped = {"after_steps": k_step, "asked": steps_asked, "reason": str(e)[-300:]}
+            print("bench: stopped after %d of %d steps: %s" % (k_step, steps_asked, e), file=sys.stderr, flush=True)
+            args.steps = k_step
+            break
+        if args.workload == "S-degenerate" and rank == 0:
+            print("bench: step %d: %d LPs, %d cuts, %.1f s so far" % (k_step + 1, s["lps"], s["cuts"], time.perf_counter() - t0), file=sys.stderr, flush=True)
         step_t.append(time.perf_counter()); step_lps.append(s["lps"])
         lps += s["lps"]
         cuts += s["cuts"]
@@ -280,9 +298,13 @@ def main():
     # the counters of the timed region, before anything else runs on this engine
     snap = {"counts": eng.poly_call("counts"), "rounds_run": eng.poly_call("rounds_run"), "path_stats": eng.poly_call("path_stats"),
             "health": eng.poly_call("rounds2_health"), "starts": eng.start_stats(), "totals": eng.totals(), "r2": eng.poly_call("rounds2_stats"), "defer": eng.defer_stats()}
-    snap["live"] = int(eng.poly_dump()["pu"].sum()) if snap["counts"]["nprimal"] < 5_000_000 else -1
+    snap["live"] = int(eng.poly_dump()["pu"].sum()) if snap["counts"]["nprimal"] < 5_000_000 and stopped is None else -1
+    eng.lib.bslv_poly_largest_facet.argtypes = [ctypes.c_void_p]
+    snap["largest_facet"] = int(eng.lib.bslv_poly_largest_facet(eng._poly_h))
     if rank == 0: print("bench: timed region done (%d steps, %.3f s)" % (args.steps, dt), file=sys.stderr, flush=True)
     phase_timed = list(phase_ms)         # (a copy: one_step() keeps adding to phase_ms if the run goes on below)
+    lz1 = lazy_stats()
+    mat_ms = lz1[2] - lz0[2]             # tableau passes made on request at the end of apply() (lazy tableaux): LP work, booked under "lp_tableaux_on_request", not under the cuts
     dist_timed = list(dist_ms)
     # Everything the headline needs is measured.  Two more figures for the reader, outside the timed region (rank 0, one GPU):
     #  * long_window: the SAME run continued to 5x the steps -- S-mid never terminates, the polyhedron keeps growing, and the rate
@@ -368,7 +390,7 @@ def main():
     # second figure of merit: the cut phase (bslv_poly's half of the path).  Not HBM-bound (integer / LDS /
     # latency): reported as time per cut, cuts per pass over the polyhedron, and pair tests per second next to the
     # reference's own bslv_poly.c on one core (6.9e6/s at q=5, N=1000).
-    cut_ms = phase_timed[2] if world == 1 else dist_timed[3]       # (N > 1: every rank applies the cuts of ALL ranks: rank 0's clock)
+    cut_ms = (phase_timed[2] if world == 1 else dist_timed[3]) - mat_ms       # (N > 1: every rank applies the cuts of ALL ranks: rank 0's clock; without the tableau passes apply() makes for the kept LPs)
     passes_poly = snap["rounds_run"] - rounds0
     ps = snap["path_stats"]
     roofline_cuts = {"bound": "latency/integer (not hbm)", "kernels": "per round of independent cuts: k_r2_minit (conflict matrix, LDS) + k_r2_select3 (maximal independent set) + k_r2_assign3 + k_flags2 + k_r2_emit + k_r2_classify3 + k2_fused_t<true> (one prune per selected cut) + k_r2_k2emit; k_flags2+k_emit2+k2_fused per single cut",
@@ -381,7 +403,8 @@ def main():
                      "single_cut_pipeline_cuts": ps["single_cuts"] - ps0["single_cuts"], "hot_chunks": ps["hot_chunks"] - ps0["hot_chunks"],
                      "pair_tests_per_sec": round(pair_tests / dt, 1), "reference_pair_tests_per_sec_1core": 6.9e6,
                      "mailbox": snap["health"],
-                     "multi_kernel_prunes": snap["r2"]["fallback_prunes"] - r2s0["fallback_prunes"],
+                     "multi_kernel_prunes": (snap["r2"]["fallback_prunes"] - r2s0["fallback_prunes"]) + (ps["prune_fallbacks"] - ps0["prune_fallbacks"]),
+                     "largest_new_facet_elements": snap["largest_facet"],
                      "cuts_handed_back": snap["defer"]["handed_back"], "cuts_waiting_at_end": snap["defer"]["waiting"], "one_family_batches": snap["defer"]["one_family_batches"],
                      "note": "a round applies a maximal set of mutually independent cuts of the chunk (<= 1024 cuts) in the passes of one cut: ~250 us of dependent small launches, latency-bound (profiles/r03_cut_phase_counters.json: 64-92 % of wave cycles waiting)"}
 
@@ -483,12 +506,13 @@ def main():
                        "lp_poly_overlap": pipe is not None,
                        "tableau_slot_bytes": slot_bytes, "pool_slots": pool_slots, "batch_policy": args.policy or "6 (library default: whole families, children of the shallowest cuts of the last batch first)", "ramp_steps_untimed": ramp_steps},
             "vertices_per_sec": round(new_vertices / dt, 1), "new_vertices": new_vertices, "cuts_applied": cuts, "cuts_redundant": redundant, "vertices_confirmed": confirmed,
+            "lazy_tableaux": {"lp_passes_skipped": lz1[0] - lz0[0], "passes_made_on_request": lz1[1] - lz0[1], "note": "an LP that is finished when its tableau pass would be due keeps its pending pivots; only the LPs whose cut is applied (the parents of later LPs) get their tableau, at the end of apply() -- bslv_lpq_set_lazy / bslv_lpq_materialise"},
             "lps": lps, "pivots_per_lp": round(pivots_all / max(lps, 1), 2), "pair_tests_per_sec": round(pair_tests / dt, 1),
-            "live_vertices": live, "poly_rounds": snap["rounds_run"] - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": ({"collect": round(phase_timed[0] / args.steps, 2), "lp": round(phase_timed[1] / args.steps, 2), "cuts": round(phase_timed[2] / args.steps, 2)} if world == 1 else
+            "live_vertices": live, "poly_rounds": snap["rounds_run"] - rounds0, "lp_ms_rank0": round(lp_ms, 2), "phase_ms_per_step": ({"collect": round(phase_timed[0] / args.steps, 2), "lp": round(phase_timed[1] / args.steps, 2), "lp_tableaux_on_request": round(mat_ms / args.steps, 2), "cuts": round((phase_timed[2] - mat_ms) / args.steps, 2)} if world == 1 else
                                    {"collect": round(dist_timed[0] / args.steps, 2), "lp": round(dist_timed[1] / args.steps, 2), "allgather_incl_wait": round(dist_timed[2] / args.steps, 2), "cuts": round(dist_timed[3] / args.steps, 2), "note": "rank 0; every rank in warm_starts.per_rank"}), "update_kernel_ms_rank0": round(upd_ms, 2),
             "warm_starts": {"per_rank": per_rank, "note": "LPs whose parent's tableau was not resident on the rank that solved them start from the nearest resident tableau (else from the root tableau): the hit rate of the dealing rule"},
             "useful_vs_cpu_baseline": round(((cuts + confirmed) / dt) / cpu["value"], 1) if cpu and cpu.get("value") else None,
-            "long_window": long_window,
+            "long_window": long_window, "stopped": stopped,
             "roofline": roofline, "roofline_cuts": roofline_cuts, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

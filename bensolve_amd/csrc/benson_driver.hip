@@ -693,6 +693,11 @@ int bslv_benson_solve_local_ctx(bslv_benson *h, int ctx, double *records, int *p
     lk.unlock();
     std::vector<int> st(nl), it(nl);
     int rc;
+    {   // lazy tableaux (bslv_lpq_set_lazy): the slots of this batch get their tableau only where apply() keeps them as parents.  Not in
+        // the pipelined mode, where the next batch is solved before this one's cuts are known.  BSLV_LP_LAZY=0: every LP writes its tableau
+        static const bool lazy_ok = !(getenv("BSLV_LP_LAZY") && atoi(getenv("BSLV_LP_LAZY")) == 0);
+        if ((rc = bslv_lpq_set_lazy(h->lp, (lazy_ok && !h->mark_at_collect) ? 1 : 0))) return rc;
+    }
     if ((rc = bslv_lpq_solve_batch(h->lp, nl, src.data(), dst.data(), vlo.data(), vup.data(), st.data(), it.data()))) return rc;
     {
         // The reference's retry (bslv_lp.c:222-227: undefined -> standard basis -> solve again), in two stages.  A tableau is
@@ -843,6 +848,11 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
     // (and the batch is large -- small batches have nothing but thin rounds; every waiting cut also holds a tableau of the pool)
     const int thr = (nrec >= 512 && h->world == 1 && !h->mark_at_collect && ncut - (int)cut_src.size() < std::min(h->defer_max, h->pool_slots / 8)) ? h->defer_thr : 0;
     if ((rc = bslv_poly_set_defer(h->poly, thr))) return rc;
+    if (ncut) {       // the depth of every cut, for the order of the rounds (BSLV_R2_ORDER; unused by default)
+        std::vector<double> zs(ncut);
+        for (int c = 0; c < ncut; c++) zs[c] = info[c].z;
+        if ((rc = bslv_poly_set_cut_priorities(h->poly, ncut, zs.data()))) return rc;
+    }
     if (ncut && (rc = bslv_poly_add_cuts(h->poly, ncut, cuts.data(), nullptr, prc.data()))) return rc;
     // bookkeeping: facet ids f0.. were assigned in this order on every rank
     std::lock_guard<std::mutex> lk(h->slot_mu);
@@ -869,6 +879,7 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
         for (int c = 0; c < ncut; c++) if (info[c].src >= 0) { auto it = front_of_src.find(info[c].src); info[c].front = it != front_of_src.end() ? it->second : 0; }
     }
     long applied = 0, handed_back = 0;
+    std::vector<int> keep_slots;          // slots of this batch that later LPs will start from: the only ones that need their tableau (lazy)
     // local slot of a record: position in this rank's shard
     std::unordered_map<int, int> slot_of_src;
     for (size_t k = 0; k < B.l_pos.size(); k++) slot_of_src[B.b_idx[B.l_pos[k]]] = B.l_slot[k];
@@ -891,13 +902,18 @@ int bslv_benson_apply_ctx(bslv_benson *h, int ctx, int nrec, const double *recor
                     h->primg_d[f] = uw;
                 }
                 h->facet_slot[f] = ci.slot; h->parents.emplace_back(f, ci.slot);
+                keep_slots.push_back(ci.slot);
             }
         } else if (prc[c] == 2) {                        // handed back: its tableau stays reserved
             handed_back++;
+            if (ci.slot >= 0) keep_slots.push_back(ci.slot);
             h->deferred.push_back(bslv_benson::Deferred{std::vector<double>(&cuts[(size_t)c * q], &cuts[(size_t)(c + 1) * q]), ci.z, ci.owner, ci.slot, ci.front});
         } else if (ci.slot >= 0) h->free_slots.push_back(ci.slot);
     }
     h->tot_deferred += handed_back;
+    // (lazy tableaux) the parents-to-be get their tableau now, the slots of every other LP of the batch never do
+    if ((rc = bslv_lpq_materialise(h->lp, (int)keep_slots.size(), keep_slots.data()))) return rc;
+    if ((rc = bslv_lpq_discard_pending(h->lp))) return rc;
     for (auto &kv : slot_of_src) h->free_slots.push_back(kv.second);    // confirmed vertices: tableau not needed again
     B.l_pos.clear(); B.l_slot.clear();
     h->tot_lps += nrec;

@@ -114,6 +114,7 @@ struct BatchView {
     double *trow;           // [B][ld]   the tableau row of the selection at hand (prow then holds rows of B^-1: [B][KP][ldt])
     double *uvec;           // [B][ldt]  -K_N x_N: beta = B^-1 uvec (k_rev_u; k_init and the refresh pass of k_flush multiply by it)
     double *xfull;          // [B][N]    scratch of k_rev_u: values of the nonbasic structurals by column
+    int lazy;               // bslv_lpq_set_lazy: an LP that is finished when its pass would be due keeps its pending pivots; its slot gets the tableau only when asked for (bslv_lpq_materialise)
     unsigned long long *dbg; // BSLV_REV_PROBE & 8: 100 MHz clock ticks per phase of the dual selection of LP 0 (timing experiments)
 };
 
@@ -940,7 +941,27 @@ __global__ void k_list_pending(BatchView Bv, const int *active, int nact, int it
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nact) return;
     const int b = active[k];
-    if (Bv.npend[b] > 0 || Bv.mode[b] == MODE_REFRESH) Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b;
+    if (Bv.npend[b] > 0 || Bv.mode[b] == MODE_REFRESH) {
+        // lazy: a pass over the tableau is for LPs that go on pivoting (or work in place); one that is finished keeps its <= KP pending
+        // pivots -- values, duals and objective are all in its vectors -- and most such tableaux are never looked at again
+        if (Bv.lazy && Bv.status[b] != ST_RUNNING && Bv.src[b] != Bv.dst[b] && Bv.mode[b] != MODE_REFRESH) return;
+        Bv.work[atomicAdd(&Bv.nwork[it], 1)] = b;
+    }
+}
+// lazy: the LPs list[0..n) (batch indices) whose slot still lacks its tableau -> work list of counter slot cnt_slot
+__global__ void k_list_given(BatchView Bv, const int *list, int n, int cnt_slot)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int b = list[k];
+    if (Bv.npend[b] > 0 || !Bv.flushed[b]) Bv.work[atomicAdd(&Bv.nwork[cnt_slot], 1)] = b;
+}
+// lazy: the reduced costs of every LP go to row M of its slot (k_flush would have left them there; the getters read them from there)
+__global__ void k_store_d(LpView L, BatchView Bv, int B)
+{
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && j < L.ld) L.T[(size_t)Bv.dst[b] * L.slotT + (size_t)L.M * L.ld + j] = Bv.dcur[(size_t)b * L.ld + j];
 }
 __global__ void k_after_flush(BatchView Bv, int it)
 {
@@ -1089,6 +1110,12 @@ struct bslv_lpq {
     // revised form: A once as CSC and CSR, the cost vector, per-slot reduced costs, per-LP scratch
     int *cptr_d = nullptr, *cidx_d = nullptr, *rptr_d = nullptr, *ridx_d = nullptr; double *cval_d = nullptr, *rval_d = nullptr, *cost_d = nullptr, *dsl_d = nullptr;
     unsigned long long *dbg_d = nullptr;
+    // LAZY tableaux (bslv_lpq_set_lazy; the Benson driver's mode): see bslv_lpq_materialise
+    bool lazy = false, lazy_open = false;          // lazy_open: the last batch left slots without their tableau
+    std::vector<int> last_dst;                     // dst slots of the last batch (host copy)
+    int *list_d = nullptr; int listcap = 0;
+    long lazy_skipped = 0, lazy_materialised = 0;  // LPs whose pass was skipped / asked for afterwards (totals)
+    double lazy_ms = 0;                            // host wall clock spent in bslv_lpq_materialise (total)
     double *trow_d = nullptr, *uvec_d = nullptr, *xfull_d = nullptr;
     long nnzA = 0;
     double *lb_d = nullptr, *ub_d = nullptr;
@@ -1096,6 +1123,7 @@ struct bslv_lpq {
     std::vector<double> cost;         // N+1
     // batch buffers
     int Bcap = 0;
+    int *qslot_d = nullptr;           // slots of a getter call (batch-sized, like src_d)
     int *src_d = nullptr, *dst_d = nullptr, *status_d = nullptr, *iters_d = nullptr, *mode_d = nullptr, *ver_d = nullptr;
     int *work_d = nullptr, *nwork_d = nullptr; int nworkcap = 0;
     int *npend_d = nullptr, *flushed_d = nullptr; double *pcol_d = nullptr, *dcur_d = nullptr;     // delayed update (see BatchView)
@@ -1139,20 +1167,23 @@ struct bslv_lpq {
     } ps;
 };
 
+static int materialise_indices(bslv_lpq *h, const int *list, int n);
 static int ensure_batch(bslv_lpq *h, int B)
 {
     if (B <= h->Bcap) return 0;
+    if (h->lazy_open) { const int rc = materialise_indices(h, nullptr, 0); if (rc) return rc; h->lazy_open = false; }      // (the buffers below hold the pending pivots of the last batch)
     int cap = std::max(B, h->Bcap * 2);
     // every pointer is cleared as it is freed: when one of the allocations below fails, destroy() and a later ensure_batch()
     // see nullptr for what is gone instead of freeing it a second time
     auto fr = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
-    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d); fr(h->work_d);
+    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d); fr(h->work_d); fr(h->qslot_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d);
     fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
     if (h->status_h) { (void)hipHostFree(h->status_h); h->status_h = nullptr; }
     if (h->active_h) { (void)hipHostFree(h->active_h); h->active_h = nullptr; }
     h->Bcap = 0;
     HIP_TRY(malloc0(&h->src_d, cap * sizeof(int)));
+    HIP_TRY(malloc0(&h->qslot_d, cap * sizeof(int)));
     HIP_TRY(malloc0(&h->dst_d, cap * sizeof(int)));
     HIP_TRY(malloc0(&h->status_d, cap * sizeof(int)));
     HIP_TRY(malloc0(&h->iters_d, cap * sizeof(int)));
@@ -1194,6 +1225,7 @@ static BatchView bview(bslv_lpq *h)
     v.work = h->work_d; v.nwork = h->nwork_d;
     v.dper = h->dper_d; v.pflags = h->pflags_d; v.stall = h->stall_d; v.xstat = h->xstat_d;
     v.trow = h->trow_d; v.uvec = h->uvec_d; v.xfull = h->xfull_d; v.dbg = h->dbg_d;
+    v.lazy = (h->lazy && !h->L.rev) ? 1 : 0;
     return v;
 }
 
@@ -1365,8 +1397,8 @@ void bslv_lpq_destroy(bslv_lpq *h)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
-    fr(h->dbg_d); fr(h->cptr_d); fr(h->cidx_d); fr(h->rptr_d); fr(h->ridx_d); fr(h->cval_d); fr(h->rval_d); fr(h->cost_d); fr(h->dsl_d); fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
-    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d);
+    fr(h->dbg_d); fr(h->list_d); fr(h->cptr_d); fr(h->cidx_d); fr(h->rptr_d); fr(h->ridx_d); fr(h->cval_d); fr(h->rval_d); fr(h->cost_d); fr(h->dsl_d); fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
+    fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->qslot_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d); fr(h->xstat_d); fr(h->cvals_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
     if (h->active_h) (void)hipHostFree(h->active_h);
@@ -1484,6 +1516,7 @@ int bslv_lpq_set_profile(bslv_lpq *h, int on)
 int bslv_lpq_reset_slot(bslv_lpq *h, int slot)
 {
     if (!h || slot < 0 || slot >= h->slots) { set_error("bslv_lpq_reset_slot: bad slot %d", slot); return BSLV_E_ARG; }
+    if (h->lazy_open) { const int rc = materialise_indices(h, nullptr, 0); if (rc) return rc; h->lazy_open = false; }      // (a pending pass must not land on the slot after it has been reset)
     LpView &L = h->L;
     if (L.rev) {
         const size_t nk = std::max((size_t)L.M * L.ldt, (size_t)L.ld);
@@ -1496,8 +1529,101 @@ int bslv_lpq_reset_slot(bslv_lpq *h, int slot)
     return 0;
 }
 
+// ---- lazy tableaux -----------------------------------------------------------------------------------------------------------
+// The first pass of a solve streams the parent's tableau into the LP's own slot (k_flush): 8 MB written per LP on S-mid, 17 GB per
+// batch of 2048 -- the largest single item of the LP phase -- and for nothing where nobody reads the slot again: only the LP of a
+// vertex that yields a NEW cut becomes the parent of later LPs (28 % of a batch on S-mid; the rest confirm their vertex or return a
+// cut a sibling delivered).  Values, duals and the objective of a finished LP are all in its vectors.  With bslv_lpq_set_lazy(h, 1)
+// an LP that is finished when its pass would be due keeps its pending pivots (<= KP; one that needs more passes as before), and the
+// caller names the slots it will use as parents: bslv_lpq_materialise(h, n, slots) gives those their tableau -- the same pass, the
+// same arithmetic -- and bslv_lpq_discard_pending(h) drops the rest.  A batch that is started while slots are still open gives all
+// of them their tableau first (the retry batches of the driver).  Slots that were not materialised must not be used as `src`.
+static int flush_list(bslv_lpq *h, int cnt_slot, int upper)
+{
+    LpView &L = h->L;
+    hipStream_t s = h->stream;
+    BatchView bv = bview(h);
+    const int wide = (size_t)KP * L.ldt * sizeof(double) > h->flush_lds_max;
+    const size_t lds = wide ? 0 : (size_t)KP * L.ldt * sizeof(double);
+    const bool big_flush = getenv("BSLV_FLUSH_NT") ? atoi(getenv("BSLV_FLUSH_NT")) > NT : lds > 53 * 1024;
+    const int tiles = (L.mrows + TR - 1) / TR;
+    int tr = upper * tiles >= 2048 ? 32 : (upper * tiles * 2 >= 2048 ? 16 : (upper * tiles * 4 >= 2048 ? 8 : 4));
+    if (big_flush) { const long rows = (long)upper * L.mrows; tr = rows >= 2048L * 128 ? 128 : rows >= 2048L * 64 ? 64 : rows >= 2048L * 32 ? 32 : 16; }
+    const int ntile = (L.mrows + tr - 1) / tr, fnt = big_flush ? NT_BIG : NT;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profile) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, s)); }
+    if (wide) hipLaunchKernelGGL(k_flush<true>, dim3(std::min(upper * ntile, h->upd_grid)), dim3(fnt), 0, s, L, bv, cnt_slot, ntile, tr);
+    else hipLaunchKernelGGL(k_flush<false>, dim3(std::min(upper * ntile, h->upd_grid)), dim3(fnt), lds, s, L, bv, cnt_slot, ntile, tr);
+    if (h->profile) HIP_TRY(hipEventRecord(e1, s));
+    hipLaunchKernelGGL(k_after_flush, dim3((upper + 255) / 256), dim3(256), 0, s, bv, cnt_slot);
+    HIP_TRY(hipGetLastError());
+    int n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, h->nwork_d + cnt_slot, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->last_passes += n;
+    h->lazy_materialised += n;
+    if (h->profile) { float t = 0; (void)hipEventElapsedTime(&t, e0, e1); h->last_update_ms += t; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    return 0;
+}
+// batch indices list[0..n) of the last batch (nullptr: all of it): their slots get their tableau
+static int materialise_indices(bslv_lpq *h, const int *list, int n)
+{
+    if (!h->lazy_open || (list && n == 0)) return 0;
+    hipStream_t s = h->stream;
+    BatchView bv = bview(h);
+    const int B = (int)h->last_dst.size();
+    std::vector<int> all;
+    if (!list) { all.resize(B); for (int b = 0; b < B; b++) all[b] = b; list = all.data(); n = B; }
+    if (n > h->listcap) { if (h->list_d) (void)hipFree(h->list_d); h->list_d = nullptr; HIP_TRY(malloc0s(&h->list_d, (size_t)std::max(n, 1024) * sizeof(int), s)); h->listcap = std::max(n, 1024); }
+    const int cnt_slot = h->L.maxit + 42;
+    HIP_TRY(hipMemcpyAsync(h->list_d, list, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(h->nwork_d + cnt_slot, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_list_given, dim3((n + 255) / 256), dim3(256), 0, s, bv, (const int *)h->list_d, n, cnt_slot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));              // (`all` / the caller's list may go out of scope)
+    int rc = flush_list(h, cnt_slot, n);
+    if (rc) return rc;
+    // row M again: the pass has applied the pending pivots to the row it found -- for an LP that had passed once before and finished
+    // with pivots pending that was ALREADY the final row (k_store_d at the end of the solve), now updated twice; the vector is the truth
+    hipLaunchKernelGGL(k_store_d, dim3((h->L.ld + 255) / 256, B), dim3(256), 0, s, h->L, bv, B);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo, const double *vup,
                             int cfirst, int ccnt, const double *cvals, int *status, int *iters);
+int bslv_lpq_set_lazy(bslv_lpq *h, int on)
+{
+    if (!h) return BSLV_E_ARG;
+    if (!on && h->lazy_open) { int rc = materialise_indices(h, nullptr, 0); if (rc) return rc; h->lazy_open = false; }
+    h->lazy = on != 0;
+    return 0;
+}
+int bslv_lpq_materialise(bslv_lpq *h, int n, const int *slots)
+{
+    if (!h || n < 0 || (n && !slots)) { set_error("bslv_lpq_materialise: bad argument"); return BSLV_E_ARG; }
+    if (!h->lazy_open || n == 0) return 0;
+    std::vector<int> idx;
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Clock { bslv_lpq *h; std::chrono::steady_clock::time_point t; ~Clock() { h->lazy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } clock{h, t0};
+    {
+        std::vector<int> where(h->slots, -1);
+        for (size_t b = 0; b < h->last_dst.size(); b++) where[h->last_dst[b]] = (int)b;
+        for (int k = 0; k < n; k++) if (slots[k] >= 0 && slots[k] < h->slots && where[slots[k]] >= 0) idx.push_back(where[slots[k]]);      // (slots of earlier batches have theirs)
+    }
+    return materialise_indices(h, idx.data(), (int)idx.size());
+}
+int bslv_lpq_discard_pending(bslv_lpq *h)
+{
+    if (!h) return BSLV_E_ARG;
+    h->lazy_open = false;
+    return 0;
+}
+int bslv_lpq_lazy_stats(const bslv_lpq *h, long out[3])
+{
+    if (!h || !out) return BSLV_E_ARG;
+    out[0] = h->lazy_skipped; out[1] = h->lazy_materialised; out[2] = (long)(h->lazy_ms * 1000.0);
+    return 0;
+}
 int bslv_lpq_solve_batch(bslv_lpq *h, int B, const int *src, const int *dst, const double *vlo,
                          const double *vup, int *status, int *iters)
 {
@@ -1538,6 +1664,10 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
             return BSLV_E_ARG;
         }
     int rc;
+    if (h->lazy_open) {        // a batch while slots of the last one are still without their tableau (a retry of the driver): all of them get it now
+        if ((rc = materialise_indices(h, nullptr, 0))) return rc;
+        h->lazy_open = false;
+    }
     if ((rc = ensure_batch(h, B))) return rc;
     LpView &L = h->L;
     const int wide = (size_t)KP * L.ldt * sizeof(double) > h->flush_lds_max;      // pivot rows from global memory in k_flush
@@ -1667,7 +1797,14 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         h->last_passes = passes;
     }
     if (L.rev) hipLaunchKernelGGL(k_rev_store_d, dim3((L.ld + 255) / 256, B), dim3(256), 0, s, L, bv, B);       // the reduced costs of every LP go to its slot
-    {   // tableaux of the solves that made no pivot
+    if (bv.lazy) {
+        // the slots keep what they hold; the reduced costs go to row M (the getters read them there), the rest waits for bslv_lpq_materialise
+        hipLaunchKernelGGL(k_store_d, dim3((L.ld + 255) / 256, B), dim3(256), 0, s, L, bv, B);
+        HIP_TRY(hipGetLastError());
+        h->last_dst.assign(dst, dst + B);
+        h->lazy_open = true;
+        h->lazy_skipped += B - std::min<long>(B, h->last_passes);
+    } else {   // tableaux of the solves that made no pivot
         const int cnt_slot = L.maxit + 40;
         hipLaunchKernelGGL(k_list_unpivoted, dim3((B + 255) / 256), dim3(256), 0, s, bv, B, cnt_slot);
         hipLaunchKernelGGL(k_copy_unpivoted, dim3(std::min(B * tiles, 2048)), dim3(NT), 0, s, L, bv, cnt_slot, tiles);
@@ -1723,9 +1860,9 @@ static int get_common(bslv_lpq *h, int B, const int *slot, int first, int cnt, i
     int rc;
     if ((rc = ensure_batch(h, B))) return rc;
     if ((rc = ensure_out(h, (size_t)B * cnt))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->src_d, slot, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->qslot_d, slot, B * sizeof(int), hipMemcpyHostToDevice, h->stream));      // (not src_d: the batch arrays stay what the last solve left, bslv_lpq_materialise reads them)
     int n = B * cnt;
-    hipLaunchKernelGGL(k_get, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->L, h->src_d, B, first, cnt, what, h->out_d);
+    hipLaunchKernelGGL(k_get, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->L, h->qslot_d, B, first, cnt, what, h->out_d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->out_d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1800,8 +1937,8 @@ int bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out)
     int rc;
     if ((rc = ensure_batch(h, B))) return rc;
     if ((rc = ensure_out(h, (size_t)B))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->src_d, slot, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_get_obj, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->L, h->src_d, B, h->c0, h->out_d);
+    HIP_TRY(hipMemcpyAsync(h->qslot_d, slot, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_get_obj, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->L, h->qslot_d, B, h->c0, h->out_d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->out_d, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

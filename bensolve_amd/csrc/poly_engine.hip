@@ -2872,6 +2872,9 @@ struct bslv_poly {
     Tri *bsum2 = nullptr; size_t bsum2cap = 0;
     int *fm_cnt = nullptr, *fm_list = nullptr; size_t fmcap = 0, fmlistcap = 0; int fm_min = 4096; long n_fm = 0; bool member_lists = true;
     // multi-GPU: pair space of large facets dealt to the ranks (k2_multi).  Below ~3e4 elements the two all-gathers cost more than the pair tests
+    int largest_facet = 0;            // members of the largest new facet pruned so far (any path)
+    std::vector<double> cut_prio;     // bslv_poly_set_cut_priorities: one number per cut of the NEXT bslv_poly_add_cuts (the rounds prefer small values); cleared by that call
+    int r2_order = getenv("BSLV_R2_ORDER") ? atoi(getenv("BSLV_R2_ORDER")) : 0;      // priority of a chunk's cuts in the rounds: 0 pseudo-random shuffle, 1 ascending / 2 descending cut priority (where the caller gave one)
     bool k2_noflags = getenv("BSLV_K2_NOFLAGS") != nullptr; long n_noflag_prunes = 0;     // large-facet prunes emit by testing the listed pair blocks again instead of keeping a flag per pair
     int shard_min = 32768; long n_sharded = 0; int2 *shard_e = nullptr; size_t shardcap = 0;
     int *nzlist = nullptr; size_t nzcap = 0;         // pair blocks with an adjacent pair (+ their count behind the list)      // facet-major member lists of a large new facet (k_fm_*)       // chunk totals of the two-level scan (k_scan_chunks)
@@ -3106,7 +3109,8 @@ static int k2_multi(bslv_poly *h, int nm, long long len_ub, int stamp)
     hipStream_t s = h->stream;
     int rc;
     const long long nbp = pair_G(nm - 1);
-    if (nbp > 0x7FFFFFF0ll) { set_error("new facet has too many elements (%d) for one pair launch", nm); return BSLV_E_CAPACITY; }
+    h->largest_facet = std::max(h->largest_facet, nm);
+    if (nbp > 0x7FFFFFF0ll) { set_error("new facet has too many elements (%d): more than 2^31 blocks of 256 pairs (block indices are 32-bit)", nm); return BSLV_E_CAPACITY; }
     // one flag byte per pair between the test and the ordered emission -- unless that array is out of reach (k_pair_retest_emit below)
     auto ensure_pflag = [&]() -> int {
         if ((size_t)nbp * PB > h->pflagcap) { size_t nc = std::max((size_t)nbp * PB, h->pflagcap * 2); if ((rc = grow(&h->pflag, 0, nc, s))) return rc; h->pflagcap = nc; }
@@ -3853,7 +3857,9 @@ int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal,
     for (int b = 0; b < B; b++) fids[b] = new_dual(h, val + (size_t)b * d, ideal ? ideal[b] : 0);
     if (h->batch_mode == 1 && B >= 2) {
         auto t0 = std::chrono::steady_clock::now();
+        if ((int)h->cut_prio.size() != B) h->cut_prio.clear();
         int rc = apply_cuts_rounds(h, fids, rc_out);
+        h->cut_prio.clear();
         h->tm_add_cuts += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return rc;
     }
@@ -4220,6 +4226,15 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     }
 }
 long bslv_poly_sharded_prunes(const bslv_poly *h) { return h ? h->n_sharded : 0; }
+// priorities for the cuts of the NEXT bslv_poly_add_cuts call (prio[b] for cut b; any order-inducing number, e.g. the depth z of the cut):
+// with BSLV_R2_ORDER = 1 / 2 the rounds of independent cuts give the cuts of a chunk their priority in ascending / descending order of it
+int bslv_poly_set_cut_priorities(bslv_poly *h, int n, const double *prio)
+{
+    if (!h || n < 0 || (n && !prio)) return BSLV_E_ARG;
+    h->cut_prio.assign(prio, prio + n);
+    return 0;
+}
+int bslv_poly_largest_facet(const bslv_poly *h) { return h ? h->largest_facet : 0; }      // members of the largest new facet that went through the multi-kernel prune
 long bslv_poly_noflag_prunes(const bslv_poly *h) { return h ? h->n_noflag_prunes : 0; }      // large-facet prunes that emitted by testing the listed pair blocks again (no flag byte per pair)
 long bslv_poly_rounds2_late_left(const bslv_poly *h) { return h ? h->r2_late_left : 0; }
 long bslv_poly_rounds2_torn_reads(const bslv_poly *h) { return h ? h->r2_torn_reads + h->mail_torn_reads : 0; }      // (both kinds of mailbox)

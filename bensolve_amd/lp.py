@@ -107,6 +107,29 @@ class LpEngine:
         self.lib.bslv_lpq_rows_folded.argtypes = [ctypes.c_void_p]
         return int(self.lib.bslv_lpq_rows_folded(self.h))
 
+    def set_lazy(self, on):
+        import ctypes
+        self.lib.bslv_lpq_set_lazy.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        check(self.lib.bslv_lpq_set_lazy(self.h, int(on)))
+
+    def materialise(self, slots):
+        import ctypes
+        slots = np.ascontiguousarray(slots, np.int32)
+        self.lib.bslv_lpq_materialise.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        check(self.lib.bslv_lpq_materialise(self.h, len(slots), slots.ctypes.data))
+
+    def discard_pending(self):
+        import ctypes
+        self.lib.bslv_lpq_discard_pending.argtypes = [ctypes.c_void_p]
+        check(self.lib.bslv_lpq_discard_pending(self.h))
+
+    def lazy_stats(self):
+        import ctypes
+        o = (ctypes.c_long * 3)()
+        self.lib.bslv_lpq_lazy_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        check(self.lib.bslv_lpq_lazy_stats(self.h, o))
+        return dict(skipped=int(o[0]), on_request=int(o[1]), ms=o[2] / 1000.0)
+
     def set_bounds(self, lo, up):
         lo = np.ascontiguousarray(lo, np.float64)
         up = np.ascontiguousarray(up, np.float64)

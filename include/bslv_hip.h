@@ -82,6 +82,18 @@ int  bslv_lpq_rows_folded(const bslv_lpq *h);
 int  bslv_lpq_is_revised(const bslv_lpq *h);
 int  bslv_lpq_pool_slots(const bslv_lpq *h);
 size_t bslv_lpq_slot_bytes(const bslv_lpq *h);
+/* LAZY TABLEAUX.  The first pass of a solve writes the LP's tableau into its own slot -- the largest memory item of a batch, and
+ * wasted where nobody uses the slot as a parent again (the reference keeps ONE basis and warm-starts from it, bslv_lp.c:170-173; here
+ * only the LP of a vertex that yields a new cut becomes a parent).  After bslv_lpq_set_lazy(h, 1) an LP that is finished when its
+ * pass would be due keeps its pending pivots; values, duals and objective are served from its vectors as always.  The caller then
+ * names the slots it will start later LPs from: bslv_lpq_materialise gives those their tableau (the same pass), and
+ * bslv_lpq_discard_pending drops the rest.  A slot that was not materialised must not be passed as `src`.  A solve_batch that finds
+ * slots still open materialises all of them first.  bslv_lpq_lazy_stats: [0] LP passes skipped, [1] passes made on request, [2] host
+ * microseconds spent in bslv_lpq_materialise (totals). */
+int  bslv_lpq_set_lazy(bslv_lpq *h, int on);
+int  bslv_lpq_materialise(bslv_lpq *h, int n, const int *slots);
+int  bslv_lpq_discard_pending(bslv_lpq *h);
+int  bslv_lpq_lazy_stats(const bslv_lpq *h, long out[3]);
 /* replace the shared bounds (lp_set_rows / lp_set_cols, bslv_lp.c:112-134) */
 int  bslv_lpq_set_bounds(bslv_lpq *h, const double *lb, const double *ub);
 /* put the standard basis (all aux basic; glp_std_basis, bslv_lp.c:101,225) into a slot */
@@ -158,6 +170,10 @@ int  bslv_poly_path_stats(const bslv_poly *h, long out[6]);
  * key 10 changes the threshold): every rank tests a contiguous share of the rows, the adjacent pairs found are all-gathered and
  * appended in rank order, which is the order a single GPU writes them in */
 long bslv_poly_sharded_prunes(const bslv_poly *h);
+/* one number per cut of the NEXT bslv_poly_add_cuts call (e.g. the depth z of the cut); with BSLV_R2_ORDER=1 / 2 the rounds of independent
+ * cuts rank the cuts of a chunk by it, ascending / descending, instead of by a pseudo-random shuffle (an experiment: see DESIGN.md 4e) */
+int  bslv_poly_set_cut_priorities(bslv_poly *h, int n, const double *prio);
+int  bslv_poly_largest_facet(const bslv_poly *h);     /* members of the largest new facet that went through the multi-kernel prune */
 long bslv_poly_noflag_prunes(const bslv_poly *h);      /* large-facet prunes that kept no flag byte per pair (k_pair_retest_emit) */
 /* cuts that were still untouched when a chunk's rounds ended on "no cut alive" and were handed to the one-cut pipeline instead
  * (0 in every run but one of round 2's test runs; kept as a counter so that it cannot hide) */

@@ -602,3 +602,45 @@ def test_revised_form_equals_the_tableau_form(monkeypatch, m, n, q, seed, B):
     # feasibility of the revised form's x at its optimum
     assert np.all(b["x"] >= -1e-9) and np.all(b["x"] @ prob["A"].T >= 1 - 1e-8)
     np.testing.assert_allclose(b["x"] @ prob["P"].T, b["y"], rtol=0, atol=1e-8)
+
+
+def test_lazy_tableaux_give_the_same_lps_and_the_same_children():
+    """bslv_lpq_set_lazy: an LP that is finished when its tableau pass would be due keeps its pending pivots -- objective, primal values
+    and duals come from its vectors -- and only the slots the caller names (bslv_lpq_materialise) get their tableau.  Against the eager
+    engine: the same results bit for bit for the whole batch, most passes skipped, and a second generation of LPs started from the
+    materialised slots (every third LP of the first) equal bit for bit as well -- also when the next batch arrives while slots are
+    still open (they are given their tableau first)."""
+    prob = synth.covering_vlp(200, 100, 3, 1)
+    model = P2Model(prob)
+    B = 96
+    rng = np.random.default_rng(4)
+    V = _random_V(model, prob, rng, B)
+    ub, ub2 = model.ub_for(V), model.ub_for(V * 1.05 + 0.02)
+    src = np.zeros(B, np.int32)
+    dst = np.arange(1, B + 1, dtype=np.int32)
+    keep = dst[::3].copy()
+    dst2 = np.arange(B + 1, B + 1 + len(keep), dtype=np.int32)
+    res = {}
+    for mode in ("eager", "lazy", "lazy, next batch while open"):
+        eng = LpEngine.from_model(model, pool_slots=2 * B + 2)
+        eng.reset_slot(0)
+        st0, _ = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+        assert st0[0] == 4
+        eng.set_lazy(mode != "eager")
+        st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+        assert np.all(st == 4)
+        first = [eng.obj(dst).copy(), eng.dual(dst, model.w_first, model.q).copy(), eng.primal(dst, model.y_first, model.q).copy(), eng.primal(dst, model.M, prob["n"]).copy(), it.copy()]
+        if mode == "lazy":
+            eng.materialise(keep)
+            eng.discard_pending()
+        st2, it2 = eng.solve_batch(keep, dst2, np.full((len(keep), model.r), -np.inf), ub2[::3])
+        assert np.all(st2 == 4), (mode, st2)
+        second = [eng.obj(dst2).copy(), eng.dual(dst2, model.w_first, model.q).copy(), eng.primal(dst2, model.y_first, model.q).copy(), it2.copy()]
+        res[mode] = (first, second, eng.lazy_stats())
+        eng.close()
+    for mode in ("lazy", "lazy, next batch while open"):
+        for a, b in zip(res["eager"][0] + res["eager"][1], res[mode][0] + res[mode][1]):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), mode
+    assert res["eager"][2]["skipped"] == 0
+    assert res["lazy"][2]["skipped"] > B // 2 and 0 < res["lazy"][2]["on_request"] <= len(keep) + len(keep), res["lazy"][2]
+    assert res["lazy, next batch while open"][2]["on_request"] >= res["lazy"][2]["skipped"], res
