@@ -370,12 +370,10 @@ def main():
     launches = max(lockstep, 1)
     achieved = (passes * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     per_pivot_equiv = (pivots * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
-    # HBM traffic from the PMC counters: collected in separate rocprofv3 --pmc passes (profiles/r01_pmc_k_flush.json,
+    # HBM traffic from the PMC counters: collected in separate rocprofv3 --pmc passes (profiles/r04_pmc_k_flush.json,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per tableau pass; scaled to this run's passes per launch
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_k_flush.json")
-    if not os.path.exists(pmc_file):
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_k_flush.json")
+    pmc_file = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_k_flush.json" % k) for k in (4, 3, 1)) if os.path.exists(p)), "")
     if args.workload == "S-mid" and os.path.exists(pmc_file):
         per_pass = json.load(open(pmc_file))["k_flush"]["traffic_bytes_per_pass"]
         traffic = round(per_pass * passes / launches, 0)
