@@ -292,8 +292,13 @@ __device__ __forceinline__ unsigned compress32(unsigned long long v)      // inv
     v = (v | (v >> 16)) & 0x00000000FFFFFFFFull;
     return (unsigned)v;
 }
-__device__ __forceinline__ unsigned r2_touch32(unsigned long long raw) { return compress32(raw ^ (raw >> 1)); }      // classes 01 MINUS, 10 ZERO
-__device__ __forceinline__ unsigned r2_minus32(unsigned long long raw) { return compress32(raw & ~(raw >> 1)); }     // class 01
+// The element-major words of the conflict-matrix rounds (RoundsV2::hw) hold the 32 cuts of a class word as two masks -- low half: the
+// cuts the element is not PLUS for (MINUS or ZERO), high half: the cuts it is MINUS for -- not as 32 two-bit classes: every kernel of a
+// round asks for these two masks, k_r2_minit several times per edge, and pulling the even bits out of a 64-bit word is ~30 instructions
+// each time (the kernel is bound by the instructions it issues).  r2_pack: from the two-bit classes (01 MINUS, 10 ZERO, 11 PLUS).
+__device__ __forceinline__ unsigned long long r2_pack(unsigned long long raw) { return (unsigned long long)compress32(raw ^ (raw >> 1)) | ((unsigned long long)compress32(raw & ~(raw >> 1)) << 32); }
+__device__ __forceinline__ unsigned r2_touch32(unsigned long long packed) { return (unsigned)packed; }
+__device__ __forceinline__ unsigned r2_minus32(unsigned long long packed) { return (unsigned)(packed >> 32); }
 // ---- owners of on-plane elements in a round of independent cuts (poly_rounds2_kernels.inc, "Elements shared by the cuts of a round") ----
 // What the flags / emit passes and the prunes need to know about the round: the element-major class words of the chunk (hw, wm:
 // which words hold a touch), the selected cuts as a bit mask (selw) and their number in the selection (selmap), the owner code of
