@@ -43,9 +43,9 @@ def bench_ex09_lp(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(0)
-    steps = args.steps or 5
+    steps = args.steps or 3
     warm = 1 if args.warmup is None else args.warmup
-    B = args.batch or 32
+    B = args.batch or 8
     prob = read_vlp(os.path.join(ROOT, "tests", "golden", "ex", "ex09.vlp"))
     model = P2Model(prob)
     os.environ.setdefault("BSLV_LP_REV", "1")          # (this workload IS the revised form; BSLV_LP_REV=0 python bench.py --workload ex09-lp rates the tableau form on the same LPs)
@@ -66,7 +66,7 @@ def bench_ex09_lp(args):
     bad = [0]
 
     def one_step():
-        V = v0 * rng.uniform(0.75, 0.99, size=(B, 1))          # (points on the ray through v0: moderately far from the LP the batch starts from)
+        V = v0 * rng.uniform(0.6, 0.98, size=(B, prob["q"]))          # (every coordinate scaled by itself: a few hundred to a few thousand pivots away from the LP the batch starts from; points on the ray through v0 keep its basis)
         stv, itv = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), model.ub_for(V))
         bad[0] += int((stv != 4).sum())        # (revised form: an LP whose inverse drifted comes back UNDEFINED for the caller's retry)
         return int(itv.sum()), eng.last_stats()

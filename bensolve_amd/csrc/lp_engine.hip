@@ -87,6 +87,7 @@ struct LpView {
     // delayed update, k_flush and its roofline carry over; only the tableau's column swap (entry q of every row) has no counterpart.
     // ex09: 171 MB per slot instead of 1.36 GB.  rev == 0: ldt = ld, mrows = M + 1 and everything is as before.
     int rho_off;                // rev: byte offset of the LDS copy of rho (row of B^-1 the tableau row is built from) in k_select's dynamic LDS, or -1 (does not fit: gathers from global memory)
+    int helpers, launch_id;      // revised form: workgroups per LP in k_select (1 = none besides the LP's own) that share the sparse products of a tableau row; a number per launch for their mailbox
     int rev, ldt, mrows, probe;  // probe: BSLV_REV_PROBE, timing experiments only (parts of the revised selection skipped: results are WRONG)
     double *dsl;                // rev: [slots][ld] reduced costs of each slot (the tableau form keeps them as row M of T)
     const int *cptr, *cidx; const double *cval;   // rev: CSC of A
@@ -114,6 +115,7 @@ struct BatchView {
     double *trow;           // [B][ld]   the tableau row of the selection at hand (prow then holds rows of B^-1: [B][KP][ldt])
     double *uvec;           // [B][ldt]  -K_N x_N: beta = B^-1 uvec (k_rev_u; k_init and the refresh pass of k_flush multiply by it)
     double *xfull;          // [B][N]    scratch of k_rev_u: values of the nonbasic structurals by column
+    int *hmail;             // [B][8]    revised form, helper workgroups of k_select: request word, slices done, pending count, slice ticket
     int lazy;               // bslv_lpq_set_lazy: an LP that is finished when its pass would be due keeps its pending pivots; its slot gets the tableau only when asked for (bslv_lpq_materialise)
     unsigned long long *dbg; // BSLV_REV_PROBE & 8: 100 MHz clock ticks per phase of the dual selection of LP 0 (timing experiments)
 };
@@ -373,6 +375,142 @@ __device__ __forceinline__ double hash01(int k)
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13;
     return (double)(x >> 8) * (1.0 / 16777216.0);
 }
+// ---- revised form: the tableau row as sparse products, by slices that several workgroups take ----
+// One sparse dot product per nonbasic column j in [j0, j1): row[j] = -rho[k] for a slack k = nh[j] < M, else -(rho . A_k) ... as the
+// caller's sign convention has it (K = [I | -A]: the column of structural k is -A_k; cval holds -A).  The non-zeros of a column are fetched
+// EIGHT at a time with independent loads (index, value, then the gathers from rho) and two columns are in flight per thread: entry after
+// entry, each a chain of three dependent loads, cost 0.7 ms per selection on ex09 (37 000 columns, one workgroup).
+// Slice t of ns takes the columns t, t + ns, t + 2 ns, ...: the few dense columns sit next to each other in the list and would all fall to one slice of a contiguous split.
+__device__ __forceinline__ void rev_row_slice(const LpView &L, const double *brow, const int *nh, double *row, int t_sl, int ns_sl)
+{
+    const int tid = threadIdx.x, NT = (int)blockDim.x, M = L.M, N = L.N;
+    constexpr int RU = 8;
+    auto dot8 = [&](int beg, int end) -> double {
+        double v = 0.0;
+        for (int t0 = beg; t0 < end; t0 += RU) {
+            int ix[RU]; double va[RU], rh[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) { const bool in = t0 + u < end; ix[u] = in ? L.cidx[t0 + u] : 0; va[u] = in ? L.cval[t0 + u] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < RU; u++) rh[u] = brow[ix[u]];
+#pragma unroll
+            for (int u = 0; u < RU; u++) v = fma(rh[u], va[u], v);
+        }
+        return v;
+    };
+    // A column with many non-zeros (ex09: 75 of its 36 939 columns hold 512 or 1024, the others 2 or 4) is not one thread's to sum -- 128
+    // rounds of dependent loads, 150 us, while the other 1023 threads of the workgroup wait: it goes to a queue in LDS and a whole wave
+    // takes it, 64 non-zeros per round.
+    constexpr int HEAVY = 32, HQ = 512;
+    __shared__ int hq[HQ];
+    __shared__ int hq_n;
+    if (tid == 0) hq_n = 0;
+    __syncthreads();
+    const int j1 = L.ld;
+    for (int i = tid; t_sl + ns_sl * i < j1; i += 2 * NT) {
+        const int j = t_sl + ns_sl * i, j2 = t_sl + ns_sl * (i + NT);
+        const int k1 = j < N ? nh[j] : -1, k2 = (j2 < j1 && j2 < N) ? nh[j2] : -1;
+        int b1 = k1 >= M ? L.cptr[k1 - M] : 0, e1 = k1 >= M ? L.cptr[k1 - M + 1] : 0;
+        int b2 = k2 >= M ? L.cptr[k2 - M] : 0, e2 = k2 >= M ? L.cptr[k2 - M + 1] : 0;
+        bool q1 = false, q2 = false;
+        if (e1 - b1 > HEAVY) { const int s = atomicAdd(&hq_n, 1); if (s < HQ) { hq[s] = j; q1 = true; e1 = b1; } }
+        if (e2 - b2 > HEAVY) { const int s = atomicAdd(&hq_n, 1); if (s < HQ) { hq[s] = j2; q2 = true; e2 = b2; } }
+        double v1 = (k1 >= 0 && k1 < M) ? -brow[k1] : 0.0, v2 = (k2 >= 0 && k2 < M) ? -brow[k2] : 0.0;
+        if (e1 - b1 <= RU && e2 - b2 <= RU) {             // (the usual case: both columns in one round of loads)
+            int ix[2 * RU]; double va[2 * RU], rh[2 * RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const bool i1 = b1 + u < e1, i2 = b2 + u < e2;
+                ix[u] = i1 ? L.cidx[b1 + u] : 0; va[u] = i1 ? L.cval[b1 + u] : 0.0;
+                ix[RU + u] = i2 ? L.cidx[b2 + u] : 0; va[RU + u] = i2 ? L.cval[b2 + u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * RU; u++) rh[u] = brow[ix[u]];
+#pragma unroll
+            for (int u = 0; u < RU; u++) { v1 = fma(rh[u], va[u], v1); v2 = fma(rh[RU + u], va[RU + u], v2); }
+        } else { v1 += dot8(b1, e1); v2 += dot8(b2, e2); }
+        if (!q1) row[j] = v1;
+        if (j2 < j1 && !q2) row[j2] = v2;
+    }
+    __syncthreads();
+    {
+        const int nq = min(hq_n, HQ), lane = tid & (WAVE - 1), wv = tid / WAVE, nwv = NT / WAVE;
+        for (int s = wv; s < nq; s += nwv) {
+            const int j = hq[s], k = nh[j];
+            const int beg = L.cptr[k - M], end = L.cptr[k - M + 1];
+            double v = 0.0;
+            for (int t0 = beg + lane; t0 < end; t0 += 4 * WAVE) {       // (four rounds in flight)
+                int ix[4]; double va[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int t = t0 + u * WAVE; const bool in = t < end; ix[u] = in ? L.cidx[t] : 0; va[u] = in ? L.cval[t] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) v = fma(brow[ix[u]], va[u], v);
+            }
+#pragma unroll
+            for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+            if (lane == 0) row[j] = v;
+        }
+    }
+    __syncthreads();
+}
+// The slices of a row are dealt by a ticket (hmail[3]) to whoever asks: the LP's own workgroup and its helpers -- workgroups of the same
+// k_select launch (blockIdx.y > 0) that do nothing but wait for a request.  ONE workgroup per LP is what a selection is, and on ex09 the
+// products over 36 865 columns were 300 of its 450 us.  Nothing waits for a workgroup that is not running: a slice nobody else took is
+// taken by the LP's own workgroup, so helpers that the chip has no room for (or that gave up waiting) only cost their share.
+// hmail[0]: request word = launch_id << 8 | n (n-th request of this launch; 0xFF: the launch is over), [1]: slices done, [2]: pending
+// pivots of the request (which row of prow holds rho), [3]: slice ticket.  Device-scope release / acquire around every hand-over: the
+// workgroups of one LP sit on different XCDs, each with its own L2.
+constexpr int REV_SLICE = 2048;                    // columns per slice (two per thread of a 1024-thread workgroup)
+__device__ __forceinline__ int rev_nslices(const LpView &L) { return (L.ld + REV_SLICE - 1) / REV_SLICE; }
+__device__ void rev_take_slices(const LpView &L, int *mb, const int n, const double *brow, const int *nh, double *row, unsigned long long *cnt = nullptr)
+{
+    __shared__ int s_t;
+    const int ns = rev_nslices(L);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // a ticket of request n and of no other: a helper that comes back late from request n - 1 must not take (or use up) one of n's
+            int v = __hip_atomic_load(&mb[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t = -1;
+            while ((v >> 16) == n && (v & 0xFFFF) < ns) {
+                if (__hip_atomic_compare_exchange_strong(&mb[3], &v, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { t = v & 0xFFFF; break; }
+            }
+            s_t = t;
+        }
+        __syncthreads();
+        const int t = s_t;
+        if (t < 0) break;
+        if (cnt && threadIdx.x == 0) *cnt += 1;
+        rev_row_slice(L, brow, nh, row, t, ns);
+        if (!(L.probe & 16)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // (the slice is out before it is counted)
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&mb[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ void rev_helper(const LpView &L, const BatchView &Bv, const int b)
+{
+    extern __shared__ unsigned char dyn_sel[];
+    __shared__ int s_req;
+    int *mb = Bv.hmail + (size_t)b * 8;
+    const int tid = threadIdx.x, NT = (int)blockDim.x;
+    const int slot = Bv.dst[b];
+    const int *nh = L.nh + (size_t)slot * L.N;
+    double *srho = L.rho_off >= 0 ? reinterpret_cast<double *>(dyn_sel + L.rho_off) : nullptr;
+    int last = L.launch_id << 8;
+    for (long spins = 0; spins < 20000000L; spins++) {          // (bounded: ~10 s; a helper that leaves is not missed, see above)
+        if (tid == 0) s_req = __hip_atomic_load(&mb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (relaxed: an acquire here invalidates the L2 of the XCD on every poll, for everyone on it)
+        __syncthreads();
+        const int req = s_req;
+        __syncthreads();
+        if ((req >> 8) != L.launch_id || req == last) { __builtin_amdgcn_s_sleep(8); continue; }
+        if ((req & 0xFF) == 0xFF) return;
+        last = req;
+        if (!(L.probe & 32)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (once per request: rho, the pending count and the heads as the LP's workgroup left them)
+        const int np = __hip_atomic_load(&mb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double *brow_g = Bv.prow + (size_t)b * KP * L.ldt + (size_t)np * L.ldt;
+        if (srho) { for (int c = tid; c < L.ldt; c += NT) srho[c] = brow_g[c]; __syncthreads(); }
+        if (!(L.probe & 64)) rev_take_slices(L, mb, req & 0xFF, srho ? srho : brow_g, nh, Bv.trow + (size_t)b * L.ld);
+    }
+}
 // Workgroup: NT threads; NT_BIG for rows of 1536 columns and more (S-degenerate: 2011, ex09: 36 939) -- an LP's selection is a chain
 // of passes over N entries by ONE workgroup, and four times the threads shorten every pass.
 // ONE selection of LP b by the calling workgroup (every `return` below is taken by the whole workgroup).  Returns false when the LP
@@ -427,45 +565,41 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
             __syncthreads();
             const double *brow = srho ? srho : brow_g;
             if (L.probe & 1) { for (int j = tid; j < ld; j += NT) row[j] = (j < N && nh[j] < M) ? -brow[nh[j]] : (j < N ? 1e-3 : 0.0); __syncthreads(); return; }
-            // one sparse dot product per nonbasic column.  The non-zeros of a column are fetched EIGHT at a time with independent loads
-            // (index, value, then the gathers from rho) and two columns are in flight per thread: entry after entry, each a chain of
-            // three dependent loads, cost 0.7 ms per selection on ex09 (37 000 columns, one workgroup) -- most of every pivot
-            constexpr int RU = 8;
-            auto dot8 = [&](int beg, int end) -> double {
-                double v = 0.0;
-                for (int t0 = beg; t0 < end; t0 += RU) {
-                    int ix[RU]; double va[RU], rh[RU];
-#pragma unroll
-                    for (int u = 0; u < RU; u++) { const bool in = t0 + u < end; ix[u] = in ? L.cidx[t0 + u] : 0; va[u] = in ? L.cval[t0 + u] : 0.0; }
-#pragma unroll
-                    for (int u = 0; u < RU; u++) rh[u] = brow[ix[u]];
-#pragma unroll
-                    for (int u = 0; u < RU; u++) v = fma(rh[u], va[u], v);
+            unsigned long long tf = ((L.probe & 8) && b == 0) ? wall_clock64() : 0ull;
+#define ROW_PHASE(k) do { if ((L.probe & 8) && b == 0) { __syncthreads(); if (tid == 0) { const unsigned long long tn = wall_clock64(); Bv.dbg[k] += tn - tf; tf = tn; } } } while (0)
+            if (L.helpers > 1) {
+                // hand the row out in slices (rev_take_slices): rho is in global memory (brow_g), the request goes out, this workgroup takes
+                // slices like everyone else and then waits for the ones others took
+                int *mb = Bv.hmail + (size_t)b * 8;
+                __threadfence();
+                __syncthreads();
+                ROW_PHASE(8);
+                __shared__ int s_n, s_late;
+                if (tid == 0) {
+                    const int old = __hip_atomic_load(&mb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int n = ((old >> 8) == L.launch_id ? (old & 0xFF) : 0) + 1;      // (at most 2 * KP requests per launch: far from 0xFF)
+                    s_n = n;
+                    __hip_atomic_store(&mb[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&mb[2], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&mb[3], n << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&mb[0], (L.launch_id << 8) | n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                return v;
-            };
-            for (int j = tid; j < ld; j += 2 * NT) {
-                const int j2 = j + NT;
-                const int k1 = j < N ? nh[j] : -1, k2 = j2 < N ? nh[j2] : -1;
-                const int b1 = k1 >= M ? L.cptr[k1 - M] : 0, e1 = k1 >= M ? L.cptr[k1 - M + 1] : 0;
-                const int b2 = k2 >= M ? L.cptr[k2 - M] : 0, e2 = k2 >= M ? L.cptr[k2 - M + 1] : 0;
-                double v1 = (k1 >= 0 && k1 < M) ? -brow[k1] : 0.0, v2 = (k2 >= 0 && k2 < M) ? -brow[k2] : 0.0;
-                if (e1 - b1 <= RU && e2 - b2 <= RU) {             // (the usual case: both columns in one round of loads)
-                    int ix[2 * RU]; double va[2 * RU], rh[2 * RU];
-#pragma unroll
-                    for (int u = 0; u < RU; u++) {
-                        const bool i1 = b1 + u < e1, i2 = b2 + u < e2;
-                        ix[u] = i1 ? L.cidx[b1 + u] : 0; va[u] = i1 ? L.cval[b1 + u] : 0.0;
-                        ix[RU + u] = i2 ? L.cidx[b2 + u] : 0; va[RU + u] = i2 ? L.cval[b2 + u] : 0.0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2 * RU; u++) rh[u] = brow[ix[u]];
-#pragma unroll
-                    for (int u = 0; u < RU; u++) { v1 = fma(rh[u], va[u], v1); v2 = fma(rh[RU + u], va[RU + u], v2); }
-                } else { v1 += dot8(b1, e1); v2 += dot8(b2, e2); }
-                row[j] = v1;
-                if (j2 < ld) row[j2] = v2;
-            }
+                __syncthreads();
+                ROW_PHASE(9);
+                rev_take_slices(L, mb, s_n, brow, nh, row, ((L.probe & 8) && b == 0) ? &Bv.dbg[13] : nullptr);
+                ROW_PHASE(10);
+                if (tid == 0) {
+                    const int ns = rev_nslices(L);
+                    long w = 0;
+                    while (__hip_atomic_load(&mb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ns && ++w < 50000000L) __builtin_amdgcn_s_sleep(2);      // (every slice counted here was taken by a workgroup that is running)
+                    s_late = w >= 50000000L;
+                }
+                __syncthreads();
+                ROW_PHASE(11);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (the slices the others wrote)
+                ROW_PHASE(12);
+                if (s_late) { rev_row_slice(L, brow, nh, row, 0, 1); __syncthreads(); }      // (never seen; the row is this workgroup's to deliver either way)
+            } else rev_row_slice(L, brow, nh, row, 0, 1);
         }
         __syncthreads();
     };
@@ -928,9 +1062,14 @@ __global__ __launch_bounds__(NT_BIG) void k_select(LpView L, BatchView Bv, const
 {
     if ((int)blockIdx.x >= nact) return;
     const int b = active[blockIdx.x];          // compacted list of the LPs still running
+    if (blockIdx.y > 0) { rev_helper(L, Bv, b); return; }      // (revised form: helps with the sparse products of LP b's tableau rows until told to leave)
     for (int sdx = 0; sdx < nsel; sdx++) {
         if (sdx) __syncthreads();              // (what thread 0 / every thread wrote for the LP -- status, mode, pending count, beta, reduced costs -- is read by all)
         if (!select_once<EXT>(L, Bv, b, cap2)) break;
+    }
+    if (L.helpers > 1) {                       // every path of the LP's own workgroup ends here: the helpers may go
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&Bv.hmail[(size_t)b * 8], (L.launch_id << 8) | 0xFF, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1117,6 +1256,7 @@ struct bslv_lpq {
     long lazy_skipped = 0, lazy_materialised = 0;  // LPs whose pass was skipped / asked for afterwards (totals)
     double lazy_ms = 0;                            // host wall clock spent in bslv_lpq_materialise (total)
     double *trow_d = nullptr, *uvec_d = nullptr, *xfull_d = nullptr;
+    int *hmail_d = nullptr; int launch_seq = 0;      // revised form: mailboxes of k_select's helper workgroups; launches so far
     long nnzA = 0;
     double *lb_d = nullptr, *ub_d = nullptr;
     unsigned char *art_d = nullptr;
@@ -1178,7 +1318,7 @@ static int ensure_batch(bslv_lpq *h, int B)
     auto fr = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->active_d); fr(h->work_d); fr(h->qslot_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d);
-    fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
+    fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d); fr(h->hmail_d);
     if (h->status_h) { (void)hipHostFree(h->status_h); h->status_h = nullptr; }
     if (h->active_h) { (void)hipHostFree(h->active_h); h->active_h = nullptr; }
     h->Bcap = 0;
@@ -1198,6 +1338,7 @@ static int ensure_batch(bslv_lpq *h, int B)
         HIP_TRY(malloc0(&h->trow_d, (size_t)cap * h->L.ld * sizeof(double)));
         HIP_TRY(malloc0(&h->uvec_d, (size_t)cap * h->L.ldt * sizeof(double)));
         HIP_TRY(malloc0(&h->xfull_d, (size_t)cap * h->L.N * sizeof(double)));
+        HIP_TRY(malloc0(&h->hmail_d, (size_t)cap * 8 * sizeof(int)));
     }
     HIP_TRY(malloc0(&h->desc_d, (size_t)cap * KP * sizeof(PivDesc)));
     HIP_TRY(malloc0(&h->pcol_d, (size_t)cap * KP * h->L.Mp1p * sizeof(double)));
@@ -1224,7 +1365,7 @@ static BatchView bview(bslv_lpq *h)
     v.desc = h->desc_d; v.prow = h->prow_d; v.pcol = h->pcol_d; v.dcur = h->dcur_d; v.npend = h->npend_d; v.flushed = h->flushed_d;
     v.work = h->work_d; v.nwork = h->nwork_d;
     v.dper = h->dper_d; v.pflags = h->pflags_d; v.stall = h->stall_d; v.xstat = h->xstat_d;
-    v.trow = h->trow_d; v.uvec = h->uvec_d; v.xfull = h->xfull_d; v.dbg = h->dbg_d;
+    v.trow = h->trow_d; v.uvec = h->uvec_d; v.xfull = h->xfull_d; v.dbg = h->dbg_d; v.hmail = h->hmail_d;
     v.lazy = (h->lazy && !h->L.rev) ? 1 : 0;
     return v;
 }
@@ -1397,7 +1538,7 @@ void bslv_lpq_destroy(bslv_lpq *h)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(h->L.T); fr(h->L.beta); fr(h->L.xN); fr(h->L.bh); fr(h->L.nh); fr(h->L.nstat); fr(h->L.pos);
     fr(h->Tstd); fr(h->lb_d); fr(h->ub_d); fr(h->art_d);
-    fr(h->dbg_d); fr(h->list_d); fr(h->cptr_d); fr(h->cidx_d); fr(h->rptr_d); fr(h->ridx_d); fr(h->cval_d); fr(h->rval_d); fr(h->cost_d); fr(h->dsl_d); fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d);
+    fr(h->dbg_d); fr(h->list_d); fr(h->cptr_d); fr(h->cidx_d); fr(h->rptr_d); fr(h->ridx_d); fr(h->cval_d); fr(h->rval_d); fr(h->cost_d); fr(h->dsl_d); fr(h->trow_d); fr(h->uvec_d); fr(h->xfull_d); fr(h->hmail_d);
     fr(h->src_d); fr(h->dst_d); fr(h->status_d); fr(h->iters_d); fr(h->mode_d); fr(h->ver_d); fr(h->qslot_d);
     fr(h->vlo_d); fr(h->vup_d); fr(h->prow_d); fr(h->desc_d); fr(h->out_d); fr(h->active_d); fr(h->work_d); fr(h->nwork_d); fr(h->npend_d); fr(h->flushed_d); fr(h->pcol_d); fr(h->dcur_d); fr(h->dper_d); fr(h->pflags_d); fr(h->stall_d); fr(h->xstat_d); fr(h->cvals_d);
     if (h->status_h) (void)hipHostFree(h->status_h);
@@ -1755,8 +1896,17 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
     while (running > 0 && it < L.maxit + 8 && !(max_rounds && it >= max_rounds)) {
         for (int c = 0; c < chunk; c++, it++) {
             for (int lev = 0; lev < KP; lev += sel_per_launch) {
-                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running), dim3(sel_nt), sel_lds_launch, s, L, bv, h->active_d, running, cap2, sel_per_launch);
-                else hipLaunchKernelGGL(k_select<false>, dim3(running), dim3(sel_nt), sel_lds_launch, s, L, bv, h->active_d, running, 0, sel_per_launch);
+                // revised form: helper workgroups for the sparse products of a tableau row (rev_helper), as many per LP as the chip holds
+                // beside the LPs' own workgroups without anyone waiting for a place
+                int helpers = 1;
+                if (L.rev && sel_nt == NT_BIG) {
+                    static const int hmax = getenv("BSLV_REV_HELPERS") ? std::max(1, atoi(getenv("BSLV_REV_HELPERS"))) : 32;
+                    helpers = std::max(1, std::min(std::min(hmax, (L.ld + 2047) / 2048), 256 / std::max(1, running)));
+                }
+                L.helpers = helpers;
+                L.launch_id = (++h->launch_seq) & 0x3FFFFF;
+                if (bfrt) hipLaunchKernelGGL(k_select<true>, dim3(running, helpers), dim3(sel_nt), sel_lds_launch, s, L, bv, h->active_d, running, cap2, sel_per_launch);
+                else hipLaunchKernelGGL(k_select<false>, dim3(running, helpers), dim3(sel_nt), sel_lds_launch, s, L, bv, h->active_d, running, 0, sel_per_launch);
             }
             hipLaunchKernelGGL(k_list_pending, dim3((running + 255) / 256), dim3(256), 0, s, bv, h->active_d, running, it);
             if (h->profile) {
@@ -1834,6 +1984,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         const double n = (double)std::max<unsigned long long>(dg[7], 1) * 100.0;       // ticks of 10 ns -> us per selection
         fprintf(stderr, "lp select phases (LP 0, %llu selections, us each): leaving row %.1f | tableau row %.1f | row scale + candidates %.1f | Harris pass %.1f | pivot choice %.1f | column %.1f | descriptor + vector updates %.1f\n",
                 dg[7], dg[0] / n, dg[1] / n, dg[2] / n, dg[3] / n, dg[4] / n, dg[5] / n, dg[6] / n);
+        if (L.rev) fprintf(stderr, "   tableau row with helpers: rho + release fence %.1f | request %.1f | own slices %.1f | wait for the others %.1f | acquire fence %.1f; slices taken by the LP's own workgroup %.2f of %d\n", dg[8] / n, dg[9] / n, dg[10] / n, dg[11] / n, dg[12] / n, dg[13] * 100.0 / n, (L.ld + 2047) / 2048);
     }
     {
         static const bool tm = getenv("BSLV_LP_TIMING") != nullptr;
