@@ -546,14 +546,16 @@ def test_a_row_on_a_column_with_per_lp_bounds_is_not_folded():
     eng.close()
 
 
-def _sparse_covering(m, n, q, seed, per_col=4):
-    """covering VLP with a sparse A (per_col non-zeros per column, every row hit) and sparse objectives: the shape of ex07 / ex09"""
+def _sparse_covering(m, n, q, seed, per_col=4, dense_cols=0):
+    """covering VLP with a sparse A (per_col non-zeros per column, every row hit) and sparse objectives: the shape of ex07 / ex09
+    (dense_cols: that many columns with m / 2 non-zeros, as ex09's 75 columns of 512 and 1024)"""
     rng = np.random.default_rng(seed)
     prob = synth.covering_vlp(m, n, q, seed)
     A = np.zeros((m, n))
     for j in range(n):
-        rows = rng.choice(m, size=per_col, replace=False)
-        A[rows, j] = rng.uniform(0.5, 1.5, size=per_col)
+        k = m // 2 if j < dense_cols else per_col
+        rows = rng.choice(m, size=k, replace=False)
+        A[rows, j] = rng.uniform(0.5, 1.5, size=k) * (0.2 if j < dense_cols else 1.0)
     for i in range(m):
         if not A[i].any():
             A[i, rng.integers(n)] = 1.0
@@ -563,13 +565,15 @@ def _sparse_covering(m, n, q, seed, per_col=4):
     return prob
 
 
-@pytest.mark.parametrize("m,n,q,seed,B", [(40, 300, 3, 5, 24), (90, 700, 4, 9, 48)])
-def test_revised_form_equals_the_tableau_form(monkeypatch, m, n, q, seed, B):
+@pytest.mark.parametrize("m,n,q,seed,B,dense_cols", [(40, 300, 3, 5, 24, 0), (90, 700, 4, 9, 48, 0), (120, 6000, 3, 11, 8, 6)])
+def test_revised_form_equals_the_tableau_form(monkeypatch, m, n, q, seed, B, dense_cols):
     """SURVEY 8f rank 4 (the reference hands A to the solver as COO, bslv_lp.c:60-70): for wide sparse problems the engine keeps the
     basis inverse per LP instead of the tableau and A once as CSC / CSR (BSLV_LP_REV=1 forces that form, 0 the tableau).  Same LPs
     through both: statuses, optimal values (1e-9), primal values of y and of every x, duals w, the LP identities; cold start and a
-    warm-started batch; chains of warm starts (a child of a child) included."""
-    prob = _sparse_covering(m, n, q, seed)
+    warm-started batch; chains of warm starts (a child of a child) included.  The third case has rows of more than 4096 columns and six
+    columns of 60 non-zeros: the selection runs with 1024 threads, the sparse products of a tableau row are dealt in slices to helper
+    workgroups of the same launch (rev_helper) and the dense columns are summed by whole waves (rev_row_slice)."""
+    prob = _sparse_covering(m, n, q, seed, dense_cols=dense_cols)
     model = P2Model(prob)
     rng = np.random.default_rng(seed)
     V = _random_V(model, prob, rng, B)
