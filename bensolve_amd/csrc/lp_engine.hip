@@ -51,6 +51,7 @@ void debug_note_alloc(const char *name, const void *p, size_t bytes, const char 
 constexpr int NS_L = 0, NS_U = 1, NS_F = 2, NS_S = 3;
 constexpr int ST_RUNNING = -1;
 constexpr int MODE_NONE = 0, MODE_PIVOT = 1, MODE_REFRESH = 2;
+constexpr int PRIMAL_STALL = 500;           // consecutive degenerate steps of a primal clean-up before Bland's rule takes over (until a step has a length again)
 constexpr int PF_PERT = 1, PF_PRIMAL = 2, PF_PERT_PENDING = 4, PF_USES_SHIFT = 8;   // BatchView::pflags
 constexpr int STALL_LIMIT = 3;         // consecutive degenerate pivots (dual step <= 1e-11) after which the costs are perturbed
 constexpr int PERT_MAX_USES = 3;       // perturbations per solve
@@ -660,10 +661,14 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
     }
     // anti-cycling: after `bland_after` pivots (a healthy solve needs far fewer) switch to Bland's rule --
     // smallest variable id among the infeasible rows, exact minimum ratio with smallest id among ties
-    const bool bland = Bv.iters[b] >= L.bland_after && !(pf & PF_PERT);     // (perturbed costs break the ties themselves)
+    // (and while a primal clean-up is in a streak of PRIMAL_STALL degenerate steps: ex09 in the revised form met clean-ups that cycled on a
+    //  degenerate face for 166 000 pivots, until bland_after ended them within 500.  Bland's rule from the first clean-up step on is no
+    //  answer -- 2 M pivots, it crawls while there is progress to be made -- so it holds only as long as the steps have length zero)
+    const bool bland = (Bv.iters[b] >= L.bland_after || (EXT && (pf & PF_PRIMAL) && Bv.stall[b] >= PRIMAL_STALL)) && !(pf & PF_PERT);     // (perturbed costs break the ties themselves)
     int r = -1, q = -1, nflip = 0;
     bool incr = false;                       // bound switches of this iteration already carried into beta
     bool below = false, have_col = false;
+    double pstep = 1.0;                      // length of a primal step (clean-up)
 
     if (EXT && (pf & PF_PRIMAL)) {
         // ---- primal simplex step on the true reduced costs (clean-up after a perturbation) ----
@@ -681,7 +686,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         ent = block_argmax(ent, sv, si);
         if (ent.i < 0) {
             // dual feasible: the dual selection takes over again (it concludes, or repairs what rounding left infeasible)
-            if (tid == 0) Bv.pflags[b] = pf & ~PF_PRIMAL;
+            if (tid == 0) { Bv.pflags[b] = pf & ~PF_PRIMAL; Bv.stall[b] = 0; }
             return true;
         }
         if (Bv.iters[b] >= L.maxit) {
@@ -744,6 +749,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         }
         r = lv.i >> 1;
         below = !(lv.i & 1);                   // the leaving variable goes to its lower bound
+        pstep = fabs(dq) * tstep / (1.0 + fabs(beta[M]));      // (what the step moves the objective by, relative: the ratio test's tolerance gives a degenerate step a length of 1e-9, not 0)
         fetch_row(r);
         have_col = true;
     } else {
@@ -776,7 +782,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
             pf &= ~PF_PERT;
             if (tid == 0 && (wrong1 || wrongb)) atomicAdd(&Bv.xstat[3], 1);
             if (wrong1) {
-                if (tid == 0) { Bv.pflags[b] = pf | PF_PRIMAL; if (L.trace == b) printf("lp %d it %d perturbation off -> primal clean-up\n", b, Bv.iters[b]); }
+                if (tid == 0) { Bv.pflags[b] = pf | PF_PRIMAL; Bv.stall[b] = 0; if (L.trace == b) printf("lp %d it %d perturbation off -> primal clean-up\n", b, Bv.iters[b]); }
                 return true;
             }
             if (tid == 0) Bv.pflags[b] = pf;
@@ -1010,7 +1016,7 @@ __device__ bool select_once(const LpView &L, const BatchView &Bv, const int b, c
         if constexpr (EXT) {
             if (nflip > 0) atomicAdd(&Bv.xstat[0], 1);
             if (incr) atomicAdd(&Bv.xstat[4], 1);
-            if (have_col) atomicAdd(&Bv.xstat[2], 1);
+            if (have_col) { atomicAdd(&Bv.xstat[2], 1); Bv.stall[b] = pstep <= 1e-7 ? Bv.stall[b] + 1 : 0; }      // (streak of degenerate steps of this primal clean-up)
             if (!have_col) {
                 // dual degenerate stalling: perturb the costs from the next selection on
                 int stl = fabs(dwork[q] / trq) <= 1e-11 ? Bv.stall[b] + 1 : 0;
