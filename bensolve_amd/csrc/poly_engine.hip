@@ -2833,6 +2833,7 @@ struct bslv_poly {
     Rounds2Buf *rounds2 = nullptr;    // scratch of the device-selected rounds inside a hot chunk (poly_rounds2_host.inc)
     bool rounds2_enabled = true;      // BSLV_NO_ROUNDS2=1 / bslv_poly_debug_set(h, 6, 0): hot chunks go through the single-cut pipeline
     int r2_fuse = 0;                  // (default 0: measured fastest) 1: the classification of a round's new vertices rides in the launch of its prunes (extra workgroups); 2: and the last prune workgroup to finish writes the adjacent pairs (a ticket; measured slower); 0: three launches (BSLV_R2_FUSE / debug_set key 13)
+    int r2_fork = 0;                  // 1: the classification of a round's new vertices runs on a second stream BESIDE the round's prunes (they are independent until k_r2_k2emit: the prune reads no class words, the classification writes only the class words of the new vertices), joined by an event before k_r2_k2emit (BSLV_R2_FORK / debug_set key 17)
     bool r2_spec = true;              // rounds are queued one ahead of the host (BSLV_R2_SPEC=0 / debug_set key 12: the host reads every round's mailbox before it queues the next)
     long r2_spec_void = 0;            // rounds that were queued ahead and found the device halted (bslv_poly_rounds2_stats)
     bool r2_share = true;             // (round 4) the cuts of a round may share elements that lie ON their planes: only a MINUS element makes two cuts conflict (poly_rounds2_kernels.inc, "Elements shared by the cuts of a round"); BSLV_R2_SHARE=0 / debug_set key 15: an element belongs to one cut of a round (rounds 2-3)
@@ -3709,6 +3710,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (const char *e = getenv("BSLV_R2_SHARE")) h->r2_share = atoi(e) != 0;
     if (const char *e = getenv("BSLV_R2_SPEC")) h->r2_spec = atoi(e) != 0;
     if (const char *e = getenv("BSLV_R2_FUSE")) h->r2_fuse = std::min(2, std::max(0, atoi(e)));
+    if (const char *e = getenv("BSLV_R2_FORK")) h->r2_fork = atoi(e) != 0;
     if (const char *e = getenv("BSLV_CHUNK_CUTS")) h->chunk_cuts = std::min(4096, std::max(32, atoi(e)));
     if (const char *e = getenv("BSLV_R2_MIN_CUTS")) h->r2_min_cuts = std::max(-1, atoi(e));
     if (const char *e = getenv("BSLV_R2_RULE")) h->r2_rule = atoi(e) ? 1 : 0;
@@ -4219,6 +4221,7 @@ int bslv_poly_debug_set(bslv_poly *h, int key, long value)
     case 7: h->chunk_cuts = (int)std::min(4096L, std::max(32L, value)); return 0;    /* cuts classified and applied together */
     case 10: h->shard_min = (int)std::max(2L, value); return 0;           /* multi-GPU: facets from this size on have their pair space dealt to the ranks */
     case 13: h->r2_fuse = (int)std::min(2L, std::max(0L, value)); return 0;                           /* one launch for a round's prunes + classification + pair emission (1) / three (0) */
+    case 17: h->r2_fork = value != 0; return 0;                           /* rounds: classification of the new vertices on a second stream beside the prunes (1) / one stream (0) */
     case 12: h->r2_spec = value != 0; return 0;                           /* rounds queued one ahead of the host (1) / mailbox read before every round (0) */
     case 16: h->k2_noflags = value != 0; return 0;                        /* multi-kernel prune of large facets without a flag byte per pair (forced; by itself from 4 GiB of flags on) */
     case 15: h->r2_share = value != 0; return 0;                          /* rounds: cuts may share on-plane elements (1) / every element belongs to one cut of a round (0) */

@@ -14,7 +14,7 @@ from test_poly_gpu import assert_slotwise_equal
 
 pytestmark = pytest.mark.gpu
 
-HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS", "BSLV_R2_MIS", "BSLV_R2_SPEC", "BSLV_R2_FUSE"]
+HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS", "BSLV_R2_MIS", "BSLV_R2_SPEC", "BSLV_R2_FUSE", "BSLV_R2_FORK"]
 MODES = {
     "default": {},
     "no_spec": {"BSLV_NO_SPEC": "1"},
@@ -137,6 +137,8 @@ R2_MODES = {
     "three launches, every prune through the multi-kernel path": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FUSE": "0", "BSLV_K2_LDS": "64"},
     "rounds queued ahead, short capacities (declined rounds)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_CHUNK_CUTS": "96"},
     "conflict matrix, chunks of 1024": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "1", "BSLV_CHUNK_CUTS": "1024"},
+    "new vertices classified on a second stream beside the prunes": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FORK": "1"},
+    "second stream, short capacities (declined rounds, halted queue)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FORK": "1", "BSLV_CHUNK_CUTS": "96"},
 }
 
 
