@@ -263,7 +263,7 @@ def main():
         eng.lib.bslv_lpq_lazy_stats(eng._lp_h, o)
         return [int(o[0]), int(o[1]), o[2] / 1000.0]
     lz0 = lazy_stats()
-    lps = cuts = pivots = lockstep = redundant = confirmed = passes = 0
+    lps = cuts = pivots = lockstep = redundant = confirmed = passes = flush_launches = 0
     upd_ms = 0.0
     lp_ms = 0.0
     sync()
@@ -295,6 +295,7 @@ def main():
         upd_ms += ls["update_ms"]
         lp_ms += ls["total_ms"]
         passes += ls["passes"]
+        flush_launches += ls["launches"]
     sync()
     dt = time.perf_counter() - t0
     eng.lp_call("set_profile", False)
@@ -370,7 +371,7 @@ def main():
     dims = eng.lp_dims()                 # (rows of A that were single-variable bounds are not in the LP)
     m_lp = dims["M"] - dims["rows_folded"] - q - r - 1     # rows of A in the TABLEAU (the LP layer folds rows with one non-zero into column bounds)
     alg_bytes_per_pass = 16.0 * (m_lp + r + 1) * (n + 2)
-    launches = max(lockstep, 1)
+    launches = max(flush_launches, 1)    # (every k_flush launch the HIP events bracketed: the lock-step rounds AND the passes made on request for the kept LPs -- what a kernel trace of the timed region counts)
     achieved = (passes * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     per_pivot_equiv = (pivots * alg_bytes_per_pass) / (upd_ms * 1e-3) / 1e9 if upd_ms > 0 else 0.0
     # HBM traffic from the PMC counters: collected in separate rocprofv3 --pmc passes (profiles/r04_pmc_k_flush.json,

@@ -1277,6 +1277,7 @@ struct bslv_lpq {
     double *cvals_d = nullptr; size_t cvals_cap = 0;     // objective coefficients of solve_batch_obj
     long last_ext[5] = {0, 0, 0, 0, 0};
     long last_passes = 0;              // (LP, pass) pairs of the last batch: how many tableaux k_flush read and wrote
+    long last_launches = 0;            // k_flush launches of the last batch: one per lock-step round + one per pass made on request (bslv_lpq_materialise)
     size_t select_lds_max = 64 * 1024; // dynamic LDS of k_select<true> (candidate sort of the bound flipping ratio test)
     size_t select0_lds_max = 64 * 1024; // ... of k_select<false> (revised form: rho)
     bool has_boxed = false;            // some variable outside the per-LP range has two finite, non-artificial bounds
@@ -1708,6 +1709,7 @@ static int flush_list(bslv_lpq *h, int cnt_slot, int upper)
     HIP_TRY(hipMemcpyAsync(&n, h->nwork_d + cnt_slot, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->last_passes += n;
+    h->last_launches += 1;
     h->lazy_materialised += n;
     if (h->profile) { float t = 0; (void)hipEventElapsedTime(&t, e0, e1); h->last_update_ms += t; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     return 0;
@@ -1797,7 +1799,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
 {
     if (h && h->ps.empty_box && B > 0 && status) {        // (bslv_lpq_set_bounds left a folded row no room: fold_bounds)
         for (int b = 0; b < B; b++) { status[b] = BSLV_LP_INFEASIBLE; if (iters) iters[b] = 0; }
-        h->last_iters = 0; h->last_pivots = 0; h->last_passes = 0;
+        h->last_iters = 0; h->last_pivots = 0; h->last_passes = 0; h->last_launches = 0;
         return 0;
     }
     if (!h || B < 0 || (B > 0 && (!src || !dst)) || (B > 0 && h->L.vcnt > 0 && (!vlo || !vup))) {
@@ -1976,6 +1978,7 @@ static int solve_batch_impl(bslv_lpq *h, int B, const int *src, const int *dst, 
         if (iters) memcpy(iters, itv.data(), B * sizeof(int));
     }
     h->last_iters = it;
+    h->last_launches = it;
     { int xs[5]; HIP_TRY(hipMemcpy(xs, h->xstat_d, sizeof xs, hipMemcpyDeviceToHost)); for (int k = 0; k < 5; k++) h->last_ext[k] = xs[k]; }
     if (h->profile) {
         double ms = 0;
@@ -2103,6 +2106,7 @@ int bslv_lpq_get_obj(bslv_lpq *h, int B, const int *slot, double *out)
 }
 
 long bslv_lpq_last_passes(const bslv_lpq *h) { return h ? h->last_passes : 0; }
+long bslv_lpq_last_launches(const bslv_lpq *h) { return h ? h->last_launches : 0; }
 long bslv_lpq_last_flip_updates(const bslv_lpq *h) { return h ? h->last_ext[4] : 0; }
 // The extended selection for every LP of this engine from now on (on != 0) or only where a variable is boxed (0, the default
 // below 1 GiB per tableau).  It changes the pivots taken, not the optimal value: used by the callers' retry when the plain

@@ -2208,7 +2208,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
         k2v2_sizes(V.st, S, go, nzero, nv0, ncross);
         if (blockIdx.x == 0 && threadIdx.x == 0 && V.fc_ticket) V.fc_ticket[(k2v2_round(V.st) + 1) & 1] = 0;
         if (!go || (int)blockIdx.x >= S) return;
-        cd = nullptr; dbg = nullptr; ne_dev = nullptr;
+        cd = nullptr; ne_dev = nullptr;      // (dbg, BSLV_K2_DEBUG: every prune workgroup of a round adds its phases)
     }
     if (!V2 && blockIdx.x > 0) {
         // workgroups 1.. ride along: they classify the elements against the NEXT halfspace (the prune reads no
@@ -2233,7 +2233,7 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
         }
     }
     unsigned long long t_prev = dbg ? wall_clock64() : 0ull;
-#define K2_PHASE(k) do { if (dbg && threadIdx.x == 0) { unsigned long long t_now = wall_clock64(); dbg[k] += t_now - t_prev; t_prev = t_now; } } while (0)
+#define K2_PHASE(k) do { if (dbg && threadIdx.x == 0) { unsigned long long t_now = wall_clock64(); if (V2) atomicAdd(&dbg[k], t_now - t_prev); else dbg[k] += t_now - t_prev; t_prev = t_now; } } while (0)
     __shared__ Tri lds[16];
     __shared__ unsigned s_off[K2_MAXNM];
     __shared__ int s_len[K2_MAXNM], s_mem[K2_MAXNM], s_long[K2_MAXLONG];
@@ -2252,19 +2252,30 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
         if (tid == 0) s_base = 0;
         __syncthreads();
         const int ncand = nzero + ncross;
-        for (int c0 = 0; c0 < ncand; c0 += K2T) {
-            const int c = c0 + tid;
-            int v = -1;
-            if (c < ncand) { v = c < nzero ? members[c] : nv0 + (c - nzero); if (!k2v2_member(P, v, V.cutof[v], vs, myrank)) v = -1; }
-            Tri t{v >= 0, 0, 0};
+        // every thread takes CPT CONSECUTIVE candidates (so one scan per CPT * K2T candidates keeps them in order) and has the loads of
+        // all of them in flight together: a round has 3-4 thousand candidates, which used to be four dependent load-scan-barrier trips
+        constexpr int CPT = 8;
+        for (int c0 = 0; c0 < ncand; c0 += K2T * CPT) {
+            const int cb = c0 + tid * CPT;
+            int vv[CPT], co[CPT], cnt = 0;
+#pragma unroll
+            for (int u = 0; u < CPT; u++) { const int c = cb + u; vv[u] = c < ncand ? (c < nzero ? members[c] : nv0 + (c - nzero)) : -1; }
+#pragma unroll
+            for (int u = 0; u < CPT; u++) co[u] = vv[u] >= 0 ? V.cutof[vv[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < CPT; u++) { if (vv[u] >= 0 && !k2v2_member(P, vv[u], co[u], vs, myrank)) vv[u] = -1; cnt += vv[u] >= 0; }
+            Tri t{cnt, 0, 0};
             Tri tot;
             const Tri ex = block_exscan(t, &tot, lds);
-            if (v >= 0 && s_base + ex.a < K2_MAXNM) s_mem[s_base + ex.a] = v;
+            int pos = s_base + ex.a;
+#pragma unroll
+            for (int u = 0; u < CPT; u++) if (vv[u] >= 0) { if (pos < K2_MAXNM) s_mem[pos] = vv[u]; pos++; }
             __syncthreads();
             if (tid == 0) s_base += tot.a;
             __syncthreads();
         }
         nm = s_base;
+        K2_PHASE(10);
         if (nm > K2_MAXNM) { v2_result(-1, nm); return; }          // too large for one workgroup: multi-kernel prune (the negative count says why: -1 members, -2 pair bitmap, -3 hash table, -4 bit matrix)
 #ifdef BSLV_R2_CHECK_MEMBERS
         k2v2_check_members(V, vs, s_mem, nm, members, nzero);          // debugging aid, O(nm^2): a member list never holds an element twice
@@ -2403,6 +2414,8 @@ __device__ void k2_fused_body(PolyView P, int *members, int nzero, int nv0, int 
         for (int m = tid; m < nm; m += K2T) mg[m] = s_mem[m];
         const Tri tt = block_sum(Tri{part, 0, 0}, lds);
         v2_result(tt.a, nm);
+        K2_PHASE(6);
+        if (dbg && tid == 0) { atomicAdd(&dbg[7], 1ull); atomicAdd(&dbg[8], (unsigned long long)W); atomicAdd(&dbg[9], (unsigned long long)s_nloc); atomicAdd(&dbg[11], (unsigned long long)nm); atomicMax(&dbg[12], (unsigned long long)nm); }
         return;
     }
     // P6: adjacent pairs in lexicographic order; the 32 pairs of a bitmap word are consecutive, so (i, j) is
@@ -3745,8 +3758,9 @@ void bslv_poly_destroy(bslv_poly *h)
     if (h->k2dbg) {
         unsigned long long t[16];
         if (hipMemcpy(t, h->k2dbg, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess && t[7])
-            fprintf(stderr, "k2_fused phases (us/launch over %llu launches): P0 %.2f P1 %.2f P2 %.2f P3 %.2f P4 %.2f P5 %.2f P6 %.2f | W %.1f nloc %.0f\n", t[7],
-                    t[0] * 0.01 / t[7], t[1] * 0.01 / t[7], t[2] * 0.01 / t[7], t[3] * 0.01 / t[7], t[4] * 0.01 / t[7], t[5] * 0.01 / t[7], t[6] * 0.01 / t[7], (double)t[8] / t[7], (double)t[9] / t[7]);
+            fprintf(stderr, "k2_fused phases (us/launch over %llu launches; rounds: per prune workgroup): P0a %.2f P0 %.2f P1 %.2f P2 %.2f P3 %.2f P4 %.2f P5 %.2f P6 %.2f | W %.1f nloc %.0f | members mean %.0f max %llu\n", t[7],
+                    t[10] * 0.01 / t[7], t[0] * 0.01 / t[7], t[1] * 0.01 / t[7], t[2] * 0.01 / t[7], t[3] * 0.01 / t[7], t[4] * 0.01 / t[7], t[5] * 0.01 / t[7], t[6] * 0.01 / t[7], (double)t[8] / t[7], (double)t[9] / t[7],
+                    (double)t[11] / t[7], t[12]);
         (void)hipFree(h->k2dbg);
     }
     auto fr = [](void *p) { if (p) (void)hipFree(p); };

@@ -196,8 +196,10 @@ class LpEngine:
         self.lib.bslv_lpq_last_ext_stats(self.h, ext)
         self.lib.bslv_lpq_last_passes.restype = ctypes.c_long
         self.lib.bslv_lpq_last_passes.argtypes = [ctypes.c_void_p]
+        self.lib.bslv_lpq_last_launches.restype = ctypes.c_long
+        self.lib.bslv_lpq_last_launches.argtypes = [ctypes.c_void_p]
         self.lib.bslv_lpq_last_flip_updates.restype = ctypes.c_long
         self.lib.bslv_lpq_last_flip_updates.argtypes = [ctypes.c_void_p]
-        return dict(lockstep_iters=it.value, pivots=piv.value, update_ms=ums.value, total_ms=tms.value, passes=self.lib.bslv_lpq_last_passes(self.h),
+        return dict(lockstep_iters=it.value, pivots=piv.value, update_ms=ums.value, total_ms=tms.value, passes=self.lib.bslv_lpq_last_passes(self.h), launches=self.lib.bslv_lpq_last_launches(self.h),
                     flip_iterations=ext[0], perturbations=ext[1], primal_steps=ext[2], wrong_sign_removals=ext[3],
                     flip_vector_updates=self.lib.bslv_lpq_last_flip_updates(self.h))

@@ -123,6 +123,9 @@ int  bslv_lpq_last_stats(const bslv_lpq *h, int *lockstep_iters, long *pivots, d
  * update_ms = time in k_flush (HIP events, with set_profile).  Tableau passes of the last batch, i.e. how many (LP, round)
  * pairs k_flush read and wrote: */
 long bslv_lpq_last_passes(const bslv_lpq *h);
+/* k_flush launches behind those passes: one per lock-step round, plus one per bslv_lpq_materialise that had something to do
+ * (what a kernel trace counts; update_ms / this = the average launch) */
+long bslv_lpq_last_launches(const bslv_lpq *h);
 /* extended selection of the last solve_batch (LPs with boxed variables): out[0] iterations in which boxed columns switched
  * bound (long-step ratio test), [1] cost perturbations switched on, [2] primal simplex steps, [3] perturbation removals
  * that left reduced costs of the wrong sign (what the bound switches / primal steps then repaired) */

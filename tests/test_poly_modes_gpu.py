@@ -137,6 +137,8 @@ R2_MODES = {
     "three launches, every prune through the multi-kernel path": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FUSE": "0", "BSLV_K2_LDS": "64"},
     "rounds queued ahead, short capacities (declined rounds)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_CHUNK_CUTS": "96"},
     "conflict matrix, chunks of 1024": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "1", "BSLV_CHUNK_CUTS": "1024"},
+    "rounds by the local minima of one random order (round 2's rule, no conflict matrix)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "0"},
+    "local minima, chunks of 96 (declined rounds)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "0", "BSLV_CHUNK_CUTS": "96"},
     "new vertices classified on a second stream beside the prunes": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FORK": "1"},
     "second stream, short capacities (declined rounds, halted queue)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FORK": "1", "BSLV_CHUNK_CUTS": "96"},
 }
