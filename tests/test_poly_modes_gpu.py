@@ -139,6 +139,8 @@ R2_MODES = {
     "conflict matrix, chunks of 1024": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "1", "BSLV_CHUNK_CUTS": "1024"},
     "rounds by the local minima of one random order (round 2's rule, no conflict matrix)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "0"},
     "local minima, chunks of 96 (declined rounds)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "0", "BSLV_CHUNK_CUTS": "96"},
+    "prunes and classification in one launch (measured slower, kept as an arm)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FUSE": "1"},
+    "prunes, classification and pair emission in one launch": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FUSE": "2"},
     "new vertices classified on a second stream beside the prunes": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FORK": "1"},
     "second stream, short capacities (declined rounds, halted queue)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FORK": "1", "BSLV_CHUNK_CUTS": "96"},
 }
