@@ -501,6 +501,44 @@ def test_one_selection_launch_per_pass_is_bit_identical_to_six(monkeypatch, kind
         assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
 
 
+@pytest.mark.parametrize("env", [{"BSLV_SELECT_NT": "1024"}, {"BSLV_FLUSH_NT": "1024"}, {"BSLV_UPD_GRID": "64"}, {"BSLV_LP_LAZY": "0"}],
+                         ids=lambda e: " ".join("%s=%s" % kv for kv in e.items()))
+def test_launch_shapes_do_not_change_the_lps(monkeypatch, env):
+    """The LP engine chooses its launch shapes by size: 256 or 1024 threads per selection workgroup (rows of 1536 columns and more) and
+    per tableau-pass workgroup (pivot rows beyond 53 KB of LDS), a persistent grid for the passes, lazy or eager passes.  None of them may
+    change a pivot or a bit of a result: every reduction is an argmax / min with index tie-breaks or a per-entry fma chain, nothing is
+    summed across threads.  The switches force the other shape on a problem that would not take it by itself (tuning arms: covered so that
+    they cannot go stale unnoticed, as the local-minima arm of the rounds did in round 4)."""
+    import oracle_api  # noqa: F401  (same import order as the other tests)
+    rng = np.random.default_rng(12)
+    prob = synth.covering_vlp(200, 100, 3, 1)
+    B = 96
+    model = P2Model(prob)
+    V = _random_V(model, prob, rng, B)
+    ub = model.ub_for(V)
+    res = []
+    for e in ({}, env):
+        for k in ("BSLV_SELECT_NT", "BSLV_FLUSH_NT", "BSLV_UPD_GRID", "BSLV_LP_LAZY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in e.items():
+            monkeypatch.setenv(k, v)
+        eng = LpEngine.from_model(model, pool_slots=B + 1)
+        eng.reset_slot(0)
+        st0, it0 = eng.solve_batch([0], [0], np.full((1, model.r), -np.inf), ub[:1])
+        assert st0[0] == 4
+        src = np.zeros(B, np.int32)
+        dst = np.arange(1, B + 1, dtype=np.int32)
+        st, it = eng.solve_batch(src, dst, np.full((B, model.r), -np.inf), ub)
+        assert np.all(st == 4)
+        res.append((int(it0[0]), it.copy(), eng.obj(dst).copy(), eng.dual(dst, model.w_first, model.q).copy(), eng.primal(dst, model.y_first, model.q).copy()))
+        eng.close()
+    a, b = res
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]), "pivot counts differ"
+    assert a[1].sum() > B
+    for x, y in zip(a[2:], b[2:]):
+        assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+
+
 def test_bounds_that_leave_a_folded_row_no_room_are_reported_infeasible():
     """The presolve folds a row with one non-zero into its column's bounds once, at create time.  New bounds (bslv_lpq_set_bounds:
     lp_set_rows / lp_set_cols of the reference, bslv_lp.c:112-135) that make the folded row and its column contradict each other

@@ -14,7 +14,7 @@ from test_poly_gpu import assert_slotwise_equal
 
 pytestmark = pytest.mark.gpu
 
-HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS", "BSLV_R2_MIS", "BSLV_R2_SPEC", "BSLV_R2_FUSE", "BSLV_R2_FORK"]
+HOOKS = ["BSLV_NO_SPEC", "BSLV_NO_HOT", "BSLV_CROSS_UB", "BSLV_K2_LDS", "BSLV_NO_ROUNDS2", "BSLV_R2_MIN_CUTS", "BSLV_CHUNK_CUTS", "BSLV_R2_MIS", "BSLV_R2_SPEC", "BSLV_R2_FUSE", "BSLV_R2_FORK", "BSLV_R2_RULE", "BSLV_R2_MINIT_WG", "BSLV_R2_FC_SLICES"]
 MODES = {
     "default": {},
     "no_spec": {"BSLV_NO_SPEC": "1"},
@@ -141,6 +141,9 @@ R2_MODES = {
     "local minima, chunks of 96 (declined rounds)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MIS": "0", "BSLV_CHUNK_CUTS": "96"},
     "prunes and classification in one launch (measured slower, kept as an arm)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FUSE": "1"},
     "prunes, classification and pair emission in one launch": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FUSE": "2"},
+    "stop rule over the last four rounds, tail through the single-cut pipeline": {"BSLV_R2_MIN_CUTS": "3", "BSLV_R2_RULE": "1"},
+    "conflict matrix built by 16 workgroups": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_MINIT_WG": "16"},
+    "one slice of global counters for prunes with long member lists": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FC_SLICES": "1"},
     "new vertices classified on a second stream beside the prunes": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FORK": "1"},
     "second stream, short capacities (declined rounds, halted queue)": {"BSLV_R2_MIN_CUTS": "-1", "BSLV_R2_FORK": "1", "BSLV_CHUNK_CUTS": "96"},
 }
