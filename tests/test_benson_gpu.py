@@ -505,13 +505,22 @@ def test_different_batch_rules_give_outer_approximations_of_the_same_image():
     reference-like rule (newest vertices first) wherever the image has features below eps -- fewer facets, fewer LPs.
     Both must be outer approximations of the same upper image within eps: every vertex of either polyhedron satisfies every cut of the
     other up to ~eps (Benson accepts a vertex whose LP value is <= eps, bslv_algs.c:1063; each cut is a supporting hyperplane of the
-    image).  Also with the rounds' shared on-plane elements off: three polyhedra, pairwise.  A covering problem at q = 4."""
+    image).  Also with the rounds' shared on-plane elements off: three polyhedra, pairwise; and with the rounds of a chunk ordered by the
+    depth of their cuts (BSLV_R2_ORDER = 1 / 2, an experiment that is off: DESIGN.md 4e) against the default.  A covering problem at q = 4."""
     import os
     prob = synth.covering_vlp(120, 60, 4, 11)
     eps, batch = 1e-7, 512
     res = {}
-    for name, pol, share in (("families", 6, 1), ("newest first", 1, 1), ("families, one owner per element", 6, 0)):
-        eng = BensonEngine(prob, eps=eps, pool_slots=4 * batch + 64)
+    arms = (("families", 6, 1, None), ("newest first", 1, 1, None), ("families, one owner per element", 6, 0, None),
+            ("families, rounds take the shallowest cuts of a chunk first", 6, 1, "1"), ("families, rounds take the deepest cuts first", 6, 1, "2"))
+    for name, pol, share, order in arms:
+        os.environ.pop("BSLV_R2_ORDER", None)
+        if order:
+            os.environ["BSLV_R2_ORDER"] = order          # (read when the engine is created: bslv_poly_set_cut_priorities gets the depth of every cut from the driver)
+        try:
+            eng = BensonEngine(prob, eps=eps, pool_slots=4 * batch + 64)
+        finally:
+            os.environ.pop("BSLV_R2_ORDER", None)
         eng.set_policy(pol)
         eng.poly_call("debug_set", 15, share)
         assert eng.start() == 0
@@ -525,10 +534,10 @@ def test_different_batch_rules_give_outer_approximations_of_the_same_image():
         res[name] = (X, Y, tot)
     names = list(res)
     scale = max(1.0, max(np.abs(res[n][0]).max() for n in names))
-    for a in names:
-        for b in names:
-            if a == b:
-                continue
+    pairs = [(a, b) for a in names[:3] for b in names[:3] if a != b]                     # the three rules of rounds 3-4 pairwise ...
+    pairs += [p for n in names[3:] for p in ((n, names[0]), (names[0], n))]              # ... the ordered rounds against the default
+    for a, b in pairs:
+        if True:
             X, Y = res[a][0], res[b][1]
             w = np.hstack([Y[:, :-1], 1 - Y[:, :-1].sum(axis=1, keepdims=True)])        # lowerV2upperH with c = (1, ..., 1): normal (y*_1..q-1, 1 - sum), rhs y*_q
             worst = 0.0
