@@ -2885,6 +2885,8 @@ struct bslv_poly {
     long hot_chunks = 0, hot_elems = 0, hot_edges = 0;
     long n_spec = 0, n_declined = 0, n_k2_fallback = 0, n_single = 0;     // bslv_poly_path_stats
     double tm_hot_begin = 0, tm_seq = 0, tm_hot_end = 0, tm_add_cuts = 0; long tm_seq_cuts = 0;
+    double tm_realloc = 0; long n_realloc = 0;                     // ms / count (BSLV_TIMING): element, edge and pool arrays that had to be re-allocated at twice their size
+    double tm_prep = 0, tm_classify_wait = 0, tm_newdual = 0;      // ms (BSLV_TIMING): a chunk's host preparation up to its batched classification, the wait for that classification, the dual slots of a batch
     double tm_launch[4] = {0, 0, 0, 0};      // us: queueing round A, k_emit2, all of round B, waiting for the mailbox   // host wall clock (ms), printed at destroy with BSLV_TIMING
     int *members = nullptr;           // cap
     Tri *bsum = nullptr; int bsumcap = 0;
@@ -2989,10 +2991,17 @@ static int grow_impl(const char *name, int line, T **p, size_t oldn, size_t newn
 }
 #define grow(p, ...) grow_impl(#p, __LINE__, p, __VA_ARGS__)
 
+struct ReallocClock {
+    bslv_poly *h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit ReallocClock(bslv_poly *hh) : h(hh) {}
+    ~ReallocClock();
+};
+ReallocClock::~ReallocClock() { h->tm_realloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); h->n_realloc++; }
 static int ensure_vcap(bslv_poly *h, int need)
 {
     if (need < 0 || need > 0x7FFFFF00 / 2) { set_error("polyhedron too large: more than 2^30 elements"); return BSLV_E_CAPACITY; }
     if (need <= h->P.cap) return 0;
+    ReallocClock clock(h);
     int ncap = (int)std::min<long long>(std::max<long long>(need, std::max<long long>(1024, 2ll * h->P.cap)), 0x7FFFFF00 / 2);
     PolyView &P = h->P;
     // SoA coordinates: re-stride
@@ -3024,6 +3033,7 @@ static int ensure_pool(bslv_poly *h, size_t need)
 {
     if (need <= h->poolcap) return 0;
     if (need > 0xF0000000ull) { set_error("incidence pool exceeds 32-bit offsets"); return BSLV_E_CAPACITY; }
+    ReallocClock clock(h);
     size_t ncap = std::min<size_t>(0xF0000000ull, std::max(need, std::max<size_t>(1 << 16, (size_t)h->poolcap * 2)));
     int rc;
     if ((rc = grow(&h->P.pool, h->poolused, ncap + 64, h->stream))) return rc;      // + slack for load_list
@@ -3036,6 +3046,7 @@ static int ensure_ecap(bslv_poly *h, int need)
     // edge, element and pool indices are 32-bit: refuse instead of wrapping around (a 10-dimensional degenerate image gets there)
     if (need < 0 || need > 0x7FFFFF00 / 2) { set_error("polyhedron too large: more than 2^30 edges"); return BSLV_E_CAPACITY; }
     if (need <= h->ecap) return 0;
+    ReallocClock clock(h);
     int ncap = (int)std::min<long long>(std::max<long long>(need, std::max<long long>(4096, 2ll * h->ecap)), 0x7FFFFF00 / 2);
     int rc;
     if ((rc = grow(&h->E[h->ecur], h->ne, ncap, h->stream))) return rc;
@@ -3752,6 +3763,7 @@ void bslv_poly_destroy(bslv_poly *h)
         fprintf(stderr, "poly timing: add_cuts %.1f ms | hot_begin %.1f, sequences %.1f (%ld cuts, %.1f us each), hot_end %.1f ms | %ld hot chunks, %.0f elements, %.0f edges on average\n", h->tm_add_cuts,
                 h->tm_hot_begin, h->tm_seq, h->tm_seq_cuts, h->tm_seq_cuts ? h->tm_seq * 1e3 / h->tm_seq_cuts : 0.0, h->tm_hot_end, h->hot_chunks,
                 h->hot_chunks ? (double)h->hot_elems / h->hot_chunks : 0.0, h->hot_chunks ? (double)h->hot_edges / h->hot_chunks : 0.0),
+        fprintf(stderr, "poly timing, per batch of cuts: dual slots %.2f ms, chunk preparation %.2f ms, waiting for the batched classification %.2f ms (totals); %ld re-allocations of element / edge / pool arrays, %.2f ms\n", h->tm_newdual, h->tm_prep, h->tm_classify_wait, h->n_realloc, h->tm_realloc),
         fprintf(stderr, "poly host per cut (us): queue round A %.1f, k_emit2 %.1f, round B in all %.1f, mailbox wait %.1f\n", h->tm_launch[0] / std::max(1L, h->n_single), h->tm_launch[1] / std::max(1L, h->n_single),
                 h->tm_launch[2] / std::max(1L, h->n_single), h->tm_launch[3] / std::max(1L, h->n_single));
     if (h->cutlog) fclose(h->cutlog);
@@ -3875,7 +3887,9 @@ int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal,
     }
     const int d = h->d;
     std::vector<int> fids(B);
+    const auto tnd = std::chrono::steady_clock::now();
     for (int b = 0; b < B; b++) fids[b] = new_dual(h, val + (size_t)b * d, ideal ? ideal[b] : 0);
+    h->tm_newdual += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tnd).count();
     if (h->batch_mode == 1 && B >= 2) {
         auto t0 = std::chrono::steady_clock::now();
         if ((int)h->cut_prio.size() != B) h->cut_prio.clear();
