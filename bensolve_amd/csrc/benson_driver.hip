@@ -213,6 +213,14 @@ int bslv_benson_create_ex(bslv_benson **out, int m, int n, int q, const double *
     rc = bslv_poly_create(&h->poly, q, 1 /* lowerV2upperH */, c);
     if (rc) { bslv_benson_destroy(h); return rc; }
     h->pool_slots = pool_slots;
+    if (const char *e = getenv("BSLV_RESERVE")) {        // opt-in: capacity of the polyhedron ahead of need, "elements[:edges[:pool words]]" (bslv_poly_reserve)
+        long a = 0, b = 0, c3 = 0;
+        if (sscanf(e, "%ld:%ld:%ld", &a, &b, &c3) >= 1 && a > 0) {
+            if (b <= 0) b = 4 * a;
+            if (c3 <= 0) c3 = 16 * a;
+            if ((rc = bslv_poly_reserve(h->poly, a, b, c3))) { bslv_benson_destroy(h); return rc; }
+        }
+    }
     if (const char *e = getenv("BSLV_POLICY")) {         // tuning: "policy[:a[:b]]" -- 3:cap:window, 4:fronts:cap, 6:mode:batches
         int pol = 0, a = -1, b = -1, c4 = -1;
         if (sscanf(e, "%d:%d:%d:%d", &pol, &a, &b, &c4) >= 1 && pol >= 1 && pol <= 6) {

@@ -4270,6 +4270,22 @@ int bslv_poly_set_cut_priorities(bslv_poly *h, int n, const double *prio)
     h->cut_prio.assign(prio, prio + n);
     return 0;
 }
+// Capacity ahead of need: element, edge and incidence-pool arrays double when they fill up, and every doubling is a hipMalloc + copy +
+// hipFree with a stream synchronisation in the middle of a batch of cuts (~0.5 ms each, 4.5 % of S-mid's cut phase: DESIGN.md 4e item 10).
+// A caller that knows it is about to run thousands of steps reserves once.  Not while a chunk is open (the rounds hold views of the arrays).
+// Zeros leave that capacity alone; nothing ever shrinks.
+int bslv_poly_reserve(bslv_poly *h, long elements, long edges, long pool_words)
+{
+    if (!h || elements < 0 || edges < 0 || pool_words < 0) return BSLV_E_ARG;
+    if (h->hot) { set_error("bslv_poly_reserve: a chunk of cuts is open"); return BSLV_E_ARG; }
+    if (elements > 0x7FFFFF00 / 2 || edges > 0x7FFFFF00 / 2 || (unsigned long)pool_words > 0xF0000000ul) { set_error("bslv_poly_reserve: beyond the 32-bit indices of the engine"); return BSLV_E_CAPACITY; }
+    int rc;
+    if (elements > h->P.cap && (rc = ensure_vcap(h, (int)elements))) return rc;
+    if (edges > h->ecap && (rc = ensure_ecap(h, (int)edges))) return rc;
+    if ((size_t)pool_words > h->poolcap && (rc = ensure_pool(h, (size_t)pool_words))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
 int bslv_poly_largest_facet(const bslv_poly *h) { return h ? h->largest_facet : 0; }      // members of the largest new facet that went through the multi-kernel prune
 long bslv_poly_noflag_prunes(const bslv_poly *h) { return h ? h->n_noflag_prunes : 0; }      // large-facet prunes that emitted by testing the listed pair blocks again (no flag byte per pair)
 long bslv_poly_rounds2_late_left(const bslv_poly *h) { return h ? h->r2_late_left : 0; }

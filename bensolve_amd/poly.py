@@ -117,6 +117,12 @@ class PolyEngine:
         self.lib.bslv_poly_sharded_prunes.argtypes = [ctypes.c_void_p]
         return self.lib.bslv_poly_sharded_prunes(self.h)
 
+    def reserve(self, elements=0, edges=0, pool_words=0):
+        """capacity ahead of need (bslv_poly_reserve): the arrays otherwise double when they fill up, in the middle of a batch of cuts"""
+        self.lib.bslv_poly_reserve.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_long]
+        self.lib.bslv_poly_reserve.restype = ctypes.c_int
+        check(self.lib.bslv_poly_reserve(self.h, elements, edges, pool_words))
+
     def path_stats(self):
         out = (ctypes.c_long * 6)()
         check(self.lib.bslv_poly_path_stats(self.h, out))

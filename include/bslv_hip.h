@@ -176,6 +176,10 @@ long bslv_poly_sharded_prunes(const bslv_poly *h);
 /* one number per cut of the NEXT bslv_poly_add_cuts call (e.g. the depth z of the cut); with BSLV_R2_ORDER=1 / 2 the rounds of independent
  * cuts rank the cuts of a chunk by it, ascending / descending, instead of by a pseudo-random shuffle (an experiment: see DESIGN.md 4e) */
 int  bslv_poly_set_cut_priorities(bslv_poly *h, int n, const double *prio);
+/* capacity ahead of need (elements = vertices + directions, edges, 32-bit words of incidence lists; 0 = leave alone): the arrays otherwise
+ * double when they fill up, a hipMalloc + copy + hipFree in the middle of a batch of cuts.  The reference grows its lists the same way
+ * in blocks of VRTXBLCK / LSTBLCK (bslv_poly.c:415-440 `add_vrtx`, :452 list blocks).  BSLV_E_ARG while a chunk of cuts is open. */
+int  bslv_poly_reserve(bslv_poly *h, long elements, long edges, long pool_words);
 int  bslv_poly_largest_facet(const bslv_poly *h);     /* members of the largest new facet that went through the multi-kernel prune */
 long bslv_poly_noflag_prunes(const bslv_poly *h);      /* large-facet prunes that kept no flag byte per pair (k_pair_retest_emit) */
 /* cuts that were still untouched when a chunk's rounds ended on "no cut alive" and were handed to the one-cut pipeline instead

@@ -65,6 +65,44 @@ def test_degenerate_cube_and_crosspolytope(q):
         assert_slotwise_equal(do, dg)
 
 
+@pytest.mark.parametrize("mode,when", [(0, "before init"), (1, "before init"), (1, "between batches")])
+def test_capacity_reserved_ahead_changes_nothing(mode, when):
+    """bslv_poly_reserve: element, edge and pool arrays at their final size before the cuts arrive (no doubling in the middle of a batch)
+    give the polyhedron of the engine that grew as it went, slot for slot -- and the oracle's (the reference grows in blocks of VRTXBLCK /
+    LSTBLCK, bslv_poly.c:415-440, :452: capacity is not part of the result).  Refused with an argument error for negative sizes."""
+    q, N = 4, 400
+    D = ph.tangent_halfspaces(q, N, 21)
+    k = q + 2
+    dumps = []
+    for reserve in (False, True):
+        G = PolyEngine(q, 0, None)
+        G.set_batch_mode(mode)
+        if reserve and when == "before init":
+            G.reserve(1 << 16, 1 << 18, 1 << 21)
+        rc = [G.add(D[i], 0) for i in range(k)]
+        assert G.init() == 0
+        half = k + (N - k) // 2
+        rc += list(G.add_cuts(D[k:half], None))
+        if reserve and when == "between batches":
+            G.reserve(1 << 16, 1 << 18, 1 << 21)
+            G.reserve(0, 0, 0)                       # zeros leave everything alone
+            with pytest.raises(Exception):
+                G.reserve(-1, 0, 0)
+        rc += list(G.add_cuts(D[half:], None))
+        G.dual_adjacency()
+        dumps.append((rc, G.dump()))
+        G.close()
+    assert dumps[0][0] == dumps[1][0]
+    assert_slotwise_equal(dumps[0][1], dumps[1][1])
+    if mode == 0:
+        O = ph.FlatPoly("oracle", q, 0, None)
+        rco = ph.run_sequence(O, D, None, k)
+        O.dual_adjacency()
+        assert list(rco) == list(dumps[1][0])
+        assert_slotwise_equal(O.dump(), dumps[1][1])
+        O.close()
+
+
 def test_batched_add_cuts_matches_sequential():
     q, N = 5, 300
     D = ph.tangent_halfspaces(q, N, 12)
