@@ -4,8 +4,13 @@
  * One cut (= poly__add_vrtx on an initialised polyhedron, bslv_poly.c:104-151) is restated as:
  *   pass 1  classify every live primal element against the new halfspace hp.y >= alpha
  *           (alpha = 0 for directions): PLUS  s > a+EPS, ZERO a-EPS < s <= a+EPS, MINUS otherwise.
- *           These are the three bands of poly__cut (bslv_poly.c:573,596,666-675; POLY_EPS 1e-9);
- *           the reference's 1e-11 projection sub-band moves coordinates by < 1e-9 and is not restated.
+ *           These are the three bands of poly__cut (bslv_poly.c:573,596,666-675; POLY_EPS 1e-9).
+ *           The reference's projection sub-band (:666-674: a neighbour with s in (a + 1e-2 EPS, a + EPS]
+ *           is moved onto the hyperplane before it is treated as lying on it; coordinates move by < 1e-9)
+ *           is restated behind opoly_set_snap(p, 1) and OFF by default: the HIP engine does not have it
+ *           yet, and the oracle is the engine's slot-exact checker.  With
+ *           the switch on, the oracle is pinned against the compiled bslv_poly.c on a crafted case
+ *           (tests/test_oracle_poly.py::test_snap_band_*).
  *           No MINUS element -> the cut is redundant, its dual slot is left unused (:130-136).
  *   pass 2  edges: a MINUS-PLUS edge creates a new vertex on the hyperplane (:597-627), which
  *           inherits inc(minus) & inc(plus) plus the new facet (:634-665) and is adjacent to the
@@ -53,6 +58,8 @@ struct opoly {
     int initialised;
     ivec queue;
     long pair_tests, new_vertices;
+    int snap;                             /* opoly_set_snap: the projection sub-band of poly__cut (bslv_poly.c:666-674) */
+    long snapped;
 };
 
 /* ---- vertex -> halfspace maps ---- */
@@ -134,6 +141,9 @@ opoly *opoly_create(int dim, int v2h_kind, const double *c)
     return p;
 }
 
+void opoly_set_snap(opoly *p, int on) { p->snap = on != 0; }
+long opoly_snapped(const opoly *p) { return p->snapped; }
+
 void opoly_free(opoly *p)
 {
     if (!p) return;
@@ -211,6 +221,18 @@ static int do_cut(opoly *p, int f)
         if (p->inc[i].n > maxinc) maxinc = p->inc[i].n;
     }
     if (!nminus) { p->fused[f] = 0; free(cls); return 1; }
+    if (p->snap)                          /* only a cut that removes something walks the polyhedron (bslv_poly.c:130-131) */
+        for (int i = 0; i < nv0; i++) {
+            if (cls[i] != 0) continue;
+            double *x = p->X + (size_t)i * d;
+            double s = dotf(hp, x, d), a = p->ideal[i] ? 0.0 : alpha;
+            if (!(s > a + 1.0e-2 * POLY_EPS)) continue;
+            double mu = s - a, nn = 0.0;      /* bslv_poly.c:666-674: x -= (s - a) hp / |hp|^2, then the element lies on the hyperplane */
+            for (int j = 0; j < d; j++) nn += hp[j] * hp[j];
+            mu /= nn;
+            for (int j = 0; j < d; j++) x[j] -= mu * hp[j];
+            p->snapped++;
+        }
 
     int *scratch = (int *)malloc((maxinc + 2) * sizeof(int));
     /* pass 2: edges */

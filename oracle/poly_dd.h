@@ -60,6 +60,9 @@ void   opoly_get_dual_edges(const opoly *p, int *ab);
 /* work counters */
 long   opoly_pair_tests(const opoly *p);              /* edge_test calls so far */
 long   opoly_new_vertices(const opoly *p);            /* primal slots created by cuts */
+/* the projection sub-band of poly__cut (bslv_poly.c:666-674), off by default (see poly_dd.c's header); elements projected so far */
+void   opoly_set_snap(opoly *p, int on);
+long   opoly_snapped(const opoly *p);
 
 #ifdef __cplusplus
 }

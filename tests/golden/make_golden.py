@@ -102,6 +102,56 @@ def make_poly():
     np.savez_compressed(os.path.join(HERE, "poly_ref.npz"), **out)
 
 
+def snap_cases():
+    """Cut sequences with ONE crafted cut whose hyperplane passes delta above a live vertex that has a neighbour the cut removes
+    (bslv_poly.c:666-674: for delta in (1e-11, 1e-9] poly__cut moves that vertex onto the hyperplane; below 1e-11 it does not), followed
+    by ordinary cuts that meet the moved vertex.  The crafted cut is found on the REFERENCE's polyhedron, so only this script needs it."""
+    cases = {}
+    for q, N, seed in [(3, 40, 5), (4, 40, 6)]:
+        D = ph.tangent_halfspaces(q, N, seed)
+        P = ph.FlatPoly("ref", q, 0, None)
+        ph.run_sequence(P, D, None, q + 3)
+        d = P.dump()
+        P.close()
+        live = np.nonzero(d["pu"].astype(bool) & ~d["pi"].astype(bool))[0]
+        tail = ph.tangent_halfspaces(q, 12, seed + 100) * 0.97        # (a little deeper than the first N: they cut near the moved vertex too)
+        for delta in (5e-10, 5e-11, 5e-12):
+            rng = np.random.default_rng(seed)
+            v = None
+            for i0 in live:
+                nb = [b if a == i0 else a for a, b in d["E"] if i0 in (a, b)]
+                x0 = d["X"][i0]
+                for _ in range(200):
+                    w = rng.normal(size=q)
+                    if w @ x0 >= -1e-3:
+                        continue
+                    cand = w * ((-1 + delta) / (w @ x0))
+                    if any(d["pu"][n] and d["X"][n] @ cand < -1 - 1e-3 for n in nb):
+                        v = cand
+                        break
+                if v is not None:
+                    break
+            assert v is not None
+            assert abs((d["X"][i0] @ v + 1) - delta) < 1e-13
+            cases["snap_q%d_delta%.0e" % (q, delta)] = (q, 0, None, False, np.vstack([D, v[None], tail]), None, q + 3)
+    return cases
+
+
+def make_poly_snap():
+    out = {}
+    for name, case in snap_cases().items():
+        rcs, can = run_case("ref", case)
+        q, v2h, c, apex, vals, ideals, init_after = case
+        out[name + "/in_vals"] = np.asarray(vals, float)
+        out[name + "/in_ideals"] = np.asarray([0] * len(vals))
+        out[name + "/in_meta"] = np.array([q, v2h, int(apex), init_after])
+        out[name + "/rc"] = np.asarray(rcs)
+        for k, v in pack(can).items():
+            out[name + "/" + k] = v
+        print("poly snap", name, "primal", len(can["X"]), "dual", len(can["Y"]))
+    np.savez_compressed(os.path.join(HERE, "poly_ref_snap.npz"), **out)
+
+
 def read_objective_columns(path):
     """columns of P (the o lines of a .vlp file, bslv_vlp.c:434-457) as rows"""
     q = n = None
@@ -225,7 +275,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "large":
         make_poly_large()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "snap":
+        make_poly_snap()
+        sys.exit(0)
     make_poly()
+    make_poly_snap()
     make_poly_large()
     make_lp()
     make_hybrid()

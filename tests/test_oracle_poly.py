@@ -92,3 +92,47 @@ def test_get_vrtx_order_and_marks():
     d = P.dump()
     assert seen == sorted(seen) and len(seen) == int(d["pu"].sum())
     P.close()
+
+
+GOLD_S = np.load(os.path.join(HERE, "golden", "poly_ref_snap.npz"))
+
+
+def run_snap_case(name, snap):
+    import ctypes
+    q, v2h, apex, init_after = [int(x) for x in GOLD_S[name + "/in_meta"]]
+    P = ph.FlatPoly("oracle", q, v2h)
+    P.L.opoly_set_snap.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    P.L.opoly_snapped.argtypes = [ctypes.c_void_p]
+    P.L.opoly_snapped.restype = ctypes.c_long
+    P.L.opoly_set_snap(P.h, snap)
+    rcs = ph.run_sequence(P, GOLD_S[name + "/in_vals"], list(GOLD_S[name + "/in_ideals"]), init_after)
+    P.dual_adjacency()
+    can, moved = ph.canonical(P.dump()), P.L.opoly_snapped(P.h)
+    P.close()
+    g = lambda k: GOLD_S[name + "/" + k]
+    gold = dict(X=g("X"), pi=g("pi"), Y=g("Y"), di=g("di"), E={tuple(e) for e in g("E")}, I={tuple(e) for e in g("I")}, DE={tuple(e) for e in g("DE")})
+    assert list(rcs) == list(g("rc"))
+    return can, gold, moved
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in GOLD_S.files}))
+def test_snap_band_of_poly_cut_against_the_reference(name):
+    """bslv_poly.c:666-674: a neighbour of a removed element that lies between 1e-2 POLY_EPS and POLY_EPS above the cut is moved ONTO the
+    hyperplane before it is treated as lying on it.  Fixtures (tests/golden/make_golden.py snap, from the unmodified bslv_poly.c): one
+    crafted cut passes delta above a live vertex, twelve ordinary cuts follow.  With opoly_set_snap(1) the oracle restates the band and
+    agrees with the reference to 1e-13 -- for delta inside the band (5e-10, 5e-11: one element moved) and below it (5e-12: none moved).
+    With the switch off -- the oracle's default, and what the HIP engine computes -- the index sets are the
+    same and the coordinates differ by less than 1e-9, i.e. invisibly at the tolerance of every other comparison with the reference,
+    but by more than 1e-11 where the band is hit: the size of the gap, measured."""
+    delta = float(name.split("delta")[1])
+    can, gold, moved = run_snap_case(name, 1)
+    ph.assert_same(can, gold, rtol=0, atol=1e-13)
+    assert moved == (1 if delta > 1e-11 else 0)
+    can0, gold, moved0 = run_snap_case(name, 0)
+    assert moved0 == 0
+    ph.assert_same(can0, gold, rtol=0, atol=1e-9)
+    gap = np.abs(can0["X"] - gold["X"]).max()
+    if delta > 1e-11:
+        assert 1e-11 < gap < 1e-9, gap
+    else:
+        assert gap < 1e-13, gap
