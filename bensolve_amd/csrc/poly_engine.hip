@@ -262,6 +262,26 @@ __global__ __launch_bounds__(PB) void k_classify(PolyView P, Hp hp, int nv, int 
     classify_body(P, hp, nv, counters, zlist, blockIdx.x * PB + threadIdx.x);
 }
 
+// The projection sub-band of poly__cut (bslv_poly.c:666-674; bslv_poly_set_snap): an on-plane element that lies more than 1e-2 POLY_EPS
+// ABOVE the hyperplane of a cut that removes something is moved onto it, x -= (s - a) hp / |hp|^2, before it is treated as lying on it.
+// Runs behind k_classify of the same cut (classes and counters[0] = #MINUS are final), in front of everything that reads coordinates.
+// nn = |hp|^2 summed on the host in the reference's order; products and differences rounded separately as the reference's are.
+__global__ __launch_bounds__(PB) void k_snap(PolyView P, Hp hp, double nn, int nv, const int *counters, unsigned long long *snapped)
+{
+    if (counters[0] == 0) return;                       // a redundant cut walks nothing (bslv_poly.c:130-136)
+    const int idx = blockIdx.x * PB + threadIdx.x;
+    if (idx >= vm_count(P, nv)) return;
+    const int i = vm_id(P, idx);
+    if (!(P.flag[i] & F_USED) || P.cls[i] != 0) return;
+    double s = 0.0;
+    for (int k = 0; k < P.d; k++) s = fma(hp.h[k], P.X[(size_t)k * P.cap + i], s);
+    const double a = (P.flag[i] & F_IDEAL) ? 0.0 : hp.h[P.d];
+    if (!(s > a + 1.0e-2 * POLY_EPS)) return;
+    const double mu = __ddiv_rn(__dsub_rn(s, a), nn);
+    for (int k = 0; k < P.d; k++) P.X[(size_t)k * P.cap + i] = __dsub_rn(P.X[(size_t)k * P.cap + i], __dmul_rn(mu, hp.h[k]));
+    atomicAdd(snapped, 1ull);
+}
+
 // Batched incidence kernel: classes of nv elements against B halfspaces, 2 bits
 // each (0 dead, 1 MINUS, 2 ZERO, 3 PLUS), 32 halfspaces per 64-bit word, out[w*cap + i];
 // anyminus[w] gets bit bb set iff some live element violates halfspace 32 w + bb.  Algorithmic bytes:
@@ -2856,6 +2876,8 @@ struct bslv_poly {
     bool r2_deferred = false;         // (the last run_rounds2 stopped for that reason)
     long r2_deferred_cuts = 0, r2_doomed = 0;
     bool r2_defer_mark = !(getenv("BSLV_DEFER_MARK") && atoi(getenv("BSLV_DEFER_MARK")) == 0);   // elements a handed-back cut will remove are marked processed
+    bool snap = false;                // bslv_poly_set_snap / BSLV_POLY_SNAP: the projection sub-band of poly__cut; cuts are then applied one at a time
+    unsigned long long *snapped_d = nullptr;
     int r2_rule = 0;                  // 0: average over the rounds of the chunk so far, 1: over the last four rounds (BSLV_R2_RULE)
     int r2_min_cuts = 0;              // rounds go on while they hold at least this many cuts on average (debug_set key 8; 0: until the rounds hold one cut each; -1: always)
     long r2_rounds = 0, r2_cuts = 0, r2_fallback_prunes = 0, r2_declined = 0, r2_chunks = 0, shuffle_seq = 0, r2_late_left = 0, r2_torn_reads = 0;
@@ -3363,6 +3385,10 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
 {
     const int d = h->d, nv0 = h->nv;
     hipStream_t s = h->stream;
+    if (h->snap) {                       // every classification sees the coordinates the cuts before it left: none ahead of its turn
+        next_f = -1;
+        if (!h->snapped_d) { int rc0 = grow(&h->snapped_d, 0, 1, s, true); if (rc0) return rc0; }
+    }
     Hp hp, hn;
     memset(&hp, 0, sizeof(hp));
     memcpy(hp.h, &h->hp[(size_t)f * (d + 1)], (d + 1) * sizeof(double));
@@ -3411,6 +3437,11 @@ static int do_cut(bslv_poly *h, int f, int *rc_out, int next_f = -1)
         CutDev *cd = h->cutdev + cslot;
         auto tl0 = std::chrono::steady_clock::now();
         if (!classified) hipLaunchKernelGGL(k_classify, dim3(nbv), dim3(PB), 0, s, h->P, hp, nv0, counters, h->zlist + ZMAX * cslot, (const int *)nullptr);
+        if (h->snap && !classified) {
+            double nn = 0.0;
+            for (int k = 0; k < d; k++) nn += hp.h[k] * hp.h[k];
+            hipLaunchKernelGGL(k_snap, dim3(nbv), dim3(PB), 0, s, h->P, hp, nn, nv0, (const int *)counters, h->snapped_d);
+        }
         const int seqA = ++h->mailseq;
         const ScanArgs SA{ebsum, nbe, vbsum, nbv, h->totals + 0, h->mail_d + 0, counters, ne_ub, ne_dev, seqA, cd, h->abort_d, nv0, h->P.cap, h->poolused, h->poolcap, h->cross_ub,
                           h->pend_k2 ? (const Mail *)(h->k2mail_d + (h->pend_slot - 2)) : (const Mail *)nullptr};
@@ -3738,6 +3769,7 @@ int bslv_poly_create(bslv_poly **out, int dim, int v2h, const double *c)
     if (const char *e = getenv("BSLV_CHUNK_CUTS")) h->chunk_cuts = std::min(4096, std::max(32, atoi(e)));
     if (const char *e = getenv("BSLV_R2_MIN_CUTS")) h->r2_min_cuts = std::max(-1, atoi(e));
     if (const char *e = getenv("BSLV_R2_RULE")) h->r2_rule = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("BSLV_POLY_SNAP")) h->snap = atoi(e) != 0;
     if (const char *e = getenv("BSLV_CROSS_UB")) h->cross_ub = std::max(0, atoi(e));
     if (const char *e = getenv("BSLV_K2_LDS")) h->k2_lds = (size_t)std::max(64, atoi(e));      // test hook: a small value forces the multi-kernel prune
     if (getenv("BSLV_K2_DEBUG") && malloc0(&h->k2dbg, 16 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemset(h->k2dbg, 0, 16 * sizeof(unsigned long long));
@@ -3779,6 +3811,7 @@ void bslv_poly_destroy(bslv_poly *h)
     fr(h->P.X); fr(h->P.flag); fr(h->P.cls); fr(h->P.inc_off); fr(h->P.inc_len); fr(h->P.capx); fr(h->P.pool); fr(h->P.keep);
     fr(h->E[0]); fr(h->E[1]); fr(h->eflag); fr(h->members); fr(h->bsum); fr(h->bsum2); fr(h->fm_cnt); fr(h->fm_list); fr(h->nzlist); fr(h->totals); fr(h->counters); fr(h->ne_dev); fr(h->k2mail_d); fr(h->zlist); fr(h->zrows); fr(h->fcount); fr(h->cutdev); fr(h->abort_d);
     for (int k = 0; k < 2; k++) { fr(h->hotbuf.E[k]); fr(h->hotbuf.EP[k]); }
+    fr(h->snapped_d);
     fr(h->hotbuf.eflag); fr(h->alive); fr(h->hv_d); fr(h->ecount); fr(h->lslot_d); fr(h->lbits_d); fr(h->lnslots_d);
     fr(h->shard_e); fr(h->blks); fr(h->pflag); fr(h->fstamp); fr(h->flocal); fr(h->nlocal); fr(h->bits); fr(h->hps_d); fr(h->clsw); fr(h->anyminus); fr(h->idx_d); fr(h->val_d); fr(h->fl_d); fr(h->par_d); fr(h->r2f_d); fr(h->fhist_d); fr(h->chosen_d);
     if (h->rounds) { rounds_free(*h->rounds); delete h->rounds; }
@@ -3890,6 +3923,11 @@ int bslv_poly_add_cuts(bslv_poly *h, int B, const double *val, const int *ideal,
     const auto tnd = std::chrono::steady_clock::now();
     for (int b = 0; b < B; b++) fids[b] = new_dual(h, val + (size_t)b * d, ideal ? ideal[b] : 0);
     h->tm_newdual += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tnd).count();
+    if (h->snap) {                       // the reference's order exactly: a moved element meets the next cut where the last one left it
+        h->cut_prio.clear();
+        for (int b = 0; b < B; b++) { int r, rc = do_cut(h, fids[b], &r, -1); if (rc) return rc; rc_out[b] = r; }
+        return settle_k2(h);
+    }
     if (h->batch_mode == 1 && B >= 2) {
         auto t0 = std::chrono::steady_clock::now();
         if ((int)h->cut_prio.size() != B) h->cut_prio.clear();
@@ -4274,6 +4312,27 @@ int bslv_poly_set_cut_priorities(bslv_poly *h, int n, const double *prio)
 // hipFree with a stream synchronisation in the middle of a batch of cuts (~0.5 ms each, 4.5 % of S-mid's cut phase: DESIGN.md 4e item 10).
 // A caller that knows it is about to run thousands of steps reserves once.  Not while a chunk is open (the rounds hold views of the arrays).
 // Zeros leave that capacity alone; nothing ever shrinks.
+// The projection sub-band of poly__cut (bslv_poly.c:666-674), see k_snap.  Off by default: the rounds of independent cuts classify a chunk's
+// elements against all of its cuts before the first is applied, which a moved element would invalidate; with the band on, cuts are applied
+// one at a time in the order handed in, as the reference applies them.  *moved (may be NULL) receives the elements moved so far.
+int bslv_poly_set_snap(bslv_poly *h, int on)
+{
+    if (!h) return BSLV_E_ARG;
+    if (h->hot) { set_error("bslv_poly_set_snap: a chunk of cuts is open"); return BSLV_E_ARG; }
+    int rc = settle_k2(h);
+    if (rc) return rc;
+    h->pre_f = -1;                       // (a classification made ahead of its turn is not used across the switch)
+    h->snap = on != 0;
+    return 0;
+}
+int bslv_poly_snapped(bslv_poly *h, long *moved)
+{
+    if (!h || !moved) return BSLV_E_ARG;
+    unsigned long long v = 0;
+    if (h->snapped_d) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipMemcpy(&v, h->snapped_d, sizeof(v), hipMemcpyDeviceToHost)); }
+    *moved = (long)v;
+    return 0;
+}
 int bslv_poly_reserve(bslv_poly *h, long elements, long edges, long pool_words)
 {
     if (!h || elements < 0 || edges < 0 || pool_words < 0) return BSLV_E_ARG;

@@ -123,6 +123,17 @@ class PolyEngine:
         self.lib.bslv_poly_reserve.restype = ctypes.c_int
         check(self.lib.bslv_poly_reserve(self.h, elements, edges, pool_words))
 
+    def set_snap(self, on=1):
+        """the projection sub-band of poly__cut (bslv_poly.c:666-674); cuts are then applied one at a time"""
+        self.lib.bslv_poly_set_snap.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        check(self.lib.bslv_poly_set_snap(self.h, on))
+
+    def snapped(self):
+        out = ctypes.c_long()
+        self.lib.bslv_poly_snapped.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        check(self.lib.bslv_poly_snapped(self.h, ctypes.byref(out)))
+        return out.value
+
     def path_stats(self):
         out = (ctypes.c_long * 6)()
         check(self.lib.bslv_poly_path_stats(self.h, out))

@@ -176,6 +176,12 @@ long bslv_poly_sharded_prunes(const bslv_poly *h);
 /* one number per cut of the NEXT bslv_poly_add_cuts call (e.g. the depth z of the cut); with BSLV_R2_ORDER=1 / 2 the rounds of independent
  * cuts rank the cuts of a chunk by it, ascending / descending, instead of by a pseudo-random shuffle (an experiment: see DESIGN.md 4e) */
 int  bslv_poly_set_cut_priorities(bslv_poly *h, int n, const double *prio);
+/* the projection sub-band of poly__cut (bslv_poly.c:666-674): with on = 1 an element that lies between 1e-2 POLY_EPS and POLY_EPS above a cut
+ * that removes something is moved onto the hyperplane before it is treated as lying on it, exactly as the reference does, and cuts are applied
+ * one at a time in the order handed in (the rounds of independent cuts classify ahead and stay off).  Default 0: such an element keeps its
+ * coordinates (same index sets, coordinates within 1e-9: tests/test_oracle_poly.py::test_snap_band_*).  Also BSLV_POLY_SNAP=1. */
+int  bslv_poly_set_snap(bslv_poly *h, int on);
+int  bslv_poly_snapped(bslv_poly *h, long *moved);        /* elements moved so far */
 /* capacity ahead of need (elements = vertices + directions, edges, 32-bit words of incidence lists; 0 = leave alone): the arrays otherwise
  * double when they fill up, a hipMalloc + copy + hipFree in the middle of a batch of cuts.  The reference grows its lists the same way
  * in blocks of VRTXBLCK / LSTBLCK (bslv_poly.c:415-440 `add_vrtx`, :452 list blocks).  BSLV_E_ARG while a chunk of cuts is open. */

@@ -7,10 +7,12 @@
  *           These are the three bands of poly__cut (bslv_poly.c:573,596,666-675; POLY_EPS 1e-9).
  *           The reference's projection sub-band (:666-674: a neighbour with s in (a + 1e-2 EPS, a + EPS]
  *           is moved onto the hyperplane before it is treated as lying on it; coordinates move by < 1e-9)
- *           is restated behind opoly_set_snap(p, 1) and OFF by default: the HIP engine does not have it
- *           yet, and the oracle is the engine's slot-exact checker.  With
- *           the switch on, the oracle is pinned against the compiled bslv_poly.c on a crafted case
- *           (tests/test_oracle_poly.py::test_snap_band_*).
+ *           is restated behind opoly_set_snap(p, 1) and OFF by default, as it is in the HIP engine
+ *           (bslv_poly_set_snap: the engine's rounds of independent cuts classify ahead of the cuts, a
+ *           moved element would invalidate that, so the band costs the batching -- DESIGN.md section 8).
+ *           With the switch on, the oracle is pinned against the compiled bslv_poly.c on crafted cases
+ *           (tests/test_oracle_poly.py::test_snap_band_*), and the engine against both
+ *           (tests/test_poly_gpu.py::test_snap_band_*).
  *           No MINUS element -> the cut is redundant, its dual slot is left unused (:130-136).
  *   pass 2  edges: a MINUS-PLUS edge creates a new vertex on the hyperplane (:597-627), which
  *           inherits inc(minus) & inc(plus) plus the new facet (:634-665) and is adjacent to the

@@ -121,7 +121,7 @@ def test_snap_band_of_poly_cut_against_the_reference(name):
     hyperplane before it is treated as lying on it.  Fixtures (tests/golden/make_golden.py snap, from the unmodified bslv_poly.c): one
     crafted cut passes delta above a live vertex, twelve ordinary cuts follow.  With opoly_set_snap(1) the oracle restates the band and
     agrees with the reference to 1e-13 -- for delta inside the band (5e-10, 5e-11: one element moved) and below it (5e-12: none moved).
-    With the switch off -- the oracle's default, and what the HIP engine computes -- the index sets are the
+    With the switch off -- the default of the oracle and of the HIP engine (bslv_poly_set_snap) -- the index sets are the
     same and the coordinates differ by less than 1e-9, i.e. invisibly at the tolerance of every other comparison with the reference,
     but by more than 1e-11 where the band is hit: the size of the gap, measured."""
     delta = float(name.split("delta")[1])

@@ -355,3 +355,50 @@ def test_k1_on_the_matrix_pipe_is_bit_identical_to_the_scalar_kernel():
         G = PolyEngine(3)
         G.debug_set(9, 0)
         G.close()
+
+
+def test_snap_band_of_poly_cut_matches_the_reference_when_switched_on():
+    """bslv_poly.c:666-674 (bslv_poly_set_snap): an element between 1e-2 POLY_EPS and POLY_EPS above a cut that removes something is moved
+    onto the hyperplane.  Fixtures from the unmodified bslv_poly.c (tests/golden/poly_ref_snap.npz: a crafted cut 5e-10 / 5e-11 / 5e-12 above
+    a live vertex, twelve ordinary cuts behind it).  With the switch on the engine agrees with the reference to 1e-12 and with the oracle's
+    restatement of the band slot for slot, handing the cuts in one by one or as one batch; the number of moved elements is the oracle's.
+    With the switch off (the default) it agrees with the oracle's default slot for slot and with the reference at 1e-9."""
+    import ctypes
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poly_ref_snap.npz"))
+    for name in sorted({k.split("/")[0] for k in G.files}):
+        q, v2h, apex, init_after = [int(x) for x in G[name + "/in_meta"]]
+        vals = G[name + "/in_vals"]
+        g = lambda k: G[name + "/" + k]
+        gold = dict(X=g("X"), pi=g("pi"), Y=g("Y"), di=g("di"), E={tuple(e) for e in g("E")}, I={tuple(e) for e in g("I")}, DE={tuple(e) for e in g("DE")})
+        delta = float(name.split("delta")[1])
+        for snap in (1, 0):
+            O = ph.FlatPoly("oracle", q, v2h)
+            O.L.opoly_set_snap.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            O.L.opoly_snapped.argtypes = [ctypes.c_void_p]
+            O.L.opoly_snapped.restype = ctypes.c_long
+            O.L.opoly_set_snap(O.h, snap)
+            rco = ph.run_sequence(O, vals, None, init_after)
+            O.dual_adjacency()
+            do, moved_o = O.dump(), O.L.opoly_snapped(O.h)
+            O.close()
+            assert moved_o == (1 if snap and delta > 1e-11 else 0)
+            for batched in (False, True):
+                E = PolyEngine(q, v2h, None)
+                E.set_batch_mode(1 if batched else 0)
+                E.set_snap(snap)
+                if batched:
+                    rcg = [E.add(vals[i], 0) for i in range(init_after)]
+                    assert E.init() == 0
+                    rcg += list(E.add_cuts(vals[init_after:], None))
+                else:
+                    rcg = ph.run_sequence(E, vals, None, init_after)
+                E.dual_adjacency()
+                dg, moved_g = E.dump(), E.snapped()
+                E.close()
+                if snap or not batched:
+                    assert list(rcg) == list(rco) == list(g("rc"))
+                assert moved_g == moved_o
+                if snap or not batched:           # (the default's batched form = rounds of independent cuts: same sets, other slot numbers)
+                    assert_slotwise_equal(do, dg)
+                ph.assert_same(ph.canonical(dg), gold, rtol=0, atol=1e-12 if snap else 1e-9)
