@@ -21,6 +21,7 @@ struct Shadow {
     std::vector<btstrg> sltn_sent;         // primal sltn bits already handed to the engine
     bool apex_checked = false, lists_fresh = false;
     int nv_seen = 0;                       // primal slots whose coordinates the mirror already holds (refresh)
+    long moved_seen = 0;                   // elements the snap band had moved at the last refresh: one more and every slot is fetched again
 };
 std::map<const void *, Shadow *> g_by_ptr;       // poly_args*, &args->primal, &args->dual  ->  shadow
 
@@ -71,10 +72,15 @@ void refresh(Shadow *S)
     grow_side(&a->primal, S->P, (size_t)std::max(nv, 1));        // (never empty: the bit sets and arrays exist from the start)
     grow_side(&a->dual, S->D, (size_t)std::max(nf, 1));
     std::vector<unsigned char> u(std::max(nv, nf) + 1), id(std::max(nv, nf) + 1), sl(nv + 1);
-    // flags of every slot (a byte each), coordinates only of the slots that are new since the last call: a slot's coordinates never
+    // flags of every slot (a byte each), coordinates only of the slots that are new since the last call: a slot's coordinates do not
     // change (the whole array again on every poly__add_vrtx made the reference's driver quadratic in the number of slots)
     if (nv > 0 && bslv_poly_get_primal(S->eng, u.data(), id.data(), sl.data(), nullptr)) die("bslv_poly_get_primal");
     if (nv < S->nv_seen) S->nv_seen = 0;
+    {   // ... unless the snap band moved one (bslv_poly_set_snap): then all of them again
+        long moved = 0;
+        if (bslv_poly_snapped(S->eng, &moved)) die("bslv_poly_snapped");
+        if (moved != S->moved_seen) { S->nv_seen = 0; S->moved_seen = moved; }
+    }
     if (nv > S->nv_seen && bslv_poly_get_primal_range(S->eng, S->nv_seen, nv - S->nv_seen, a->primal.data + (size_t)S->nv_seen * d)) die("bslv_poly_get_primal_range");
     S->nv_seen = nv;
     for (int i = 0; i < nv; i++) { setbit(a->primal.used, i, u[i]); setbit(a->primal.ideal, i, id[i]); setbit(a->primal.sltn, i, sl[i]); }
@@ -189,6 +195,9 @@ void poly__initialise(poly_args *args)
     std::vector<double> c;
     const int mode = identify_callback((void (*)(double *, int, double *))args->dualV2primalH, d, c);
     if (bslv_poly_create(&S->eng, d, mode, c.data())) die("bslv_poly_create");
+    // poly__add_vrtx hands in one cut at a time, so the projection sub-band of poly__cut (bslv_poly.c:666-674) costs nothing here: on,
+    // and the reference's driver sees the coordinates its own engine would have left (BSLV_POLY_SNAP=0 switches it off)
+    { const char *e = getenv("BSLV_POLY_SNAP"); if (!(e && atoi(e) == 0) && bslv_poly_set_snap(S->eng, 1)) die("bslv_poly_set_snap"); }
     args->val = (double *)calloc((size_t)d, sizeof(double));
     args->val_primg_prml = args->dim_primg_prml ? (double *)calloc(args->dim_primg_prml, sizeof(double)) : nullptr;
     args->val_primg_dl = args->dim_primg_dl ? (double *)calloc(args->dim_primg_dl, sizeof(double)) : nullptr;
