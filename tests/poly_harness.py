@@ -7,6 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_POLY = os.path.join(ROOT, "oracle", "_ref", "libref_poly.so")
+REF_POLY_HIP = os.path.join(ROOT, "oracle", "_ref", "libref_poly_hip.so")
 
 CONE_POLAR, LOWER2UPPER, UPPER2LOWER = 0, 1, 2
 
@@ -36,6 +37,7 @@ def _bind(L, pre):
 
 
 _ref = None
+_compat = None
 
 
 def ref_available():
@@ -46,13 +48,19 @@ class FlatPoly:
     """opoly_* (oracle/liboracle.so) or rpoly_* (oracle/_ref/libref_poly.so)"""
 
     def __init__(self, kind, dim, v2h=CONE_POLAR, c=None):
-        global _ref
+        global _ref, _compat
         if kind == "oracle":
             import oracle_api
             self.L, self.pre = oracle_api.load(), "opoly_"
             if not getattr(self.L, "_poly_bound", False):
                 _bind(self.L, "opoly_")
                 self.L._poly_bound = True
+        elif kind == "compat":
+            # the same driver over the PRODUCT's poly__* symbols (oracle/_ref/libref_poly_hip.so; needs a GPU)
+            if _compat is None:
+                _compat = ctypes.CDLL(REF_POLY_HIP)
+                _bind(_compat, "rpoly_")
+            self.L, self.pre = _compat, "rpoly_"
         else:
             if _ref is None:
                 _ref = ctypes.CDLL(REF_POLY)

@@ -102,3 +102,36 @@ def test_c_abi_exports_the_reference_names():
                  "poly__kill", "poly__initialise_permutation", "poly__kill_permutation", "poly__vrtx2file", "poly__primg2file", "poly__adj2file", "poly__inc2file",
                  "poly__plot", "poly__polyck"):
         assert isinstance(getattr(lib, name), ctypes._CFuncPtr), name
+
+
+import poly_harness as ph
+
+needs_driver = pytest.mark.skipif(not os.path.exists(ph.REF_POLY_HIP), reason="oracle/_ref/libref_poly_hip.so is built only where /root/reference exists (it travels to the GPU box)")
+
+
+@needs_driver
+@pytest.mark.parametrize("fixture", ["poly_ref.npz", "poly_ref_snap.npz"])
+def test_cut_sequences_through_the_reference_struct_interface(fixture):
+    """The dump driver that made the polyhedron goldens from the unmodified bslv_poly.c (oracle/ref_poly_driver.c: poly__set_default_args,
+    poly__initialise, poly__add_vrtx, poly__intl_apprx, poly__update_adjacence, then the polytope structs read field by field) linked
+    against the PRODUCT's poly__* symbols instead (oracle/_ref/libref_poly_hip.so): every cut sequence of the goldens gives the return
+    codes, coordinates (1e-9) and index sets of the reference.  The snap fixtures (a cut crafted to pass 5e-10 / 5e-11 / 5e-12 above a
+    vertex, bslv_poly.c:666-674) at 1e-12: through these symbols the projection sub-band is on."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", fixture))
+    tol = 1e-12 if "snap" in fixture else 1e-9
+    for name in sorted({k.split("/")[0] for k in G.files}):
+        q, v2h, apex, init_after = [int(x) for x in G[name + "/in_meta"]]
+        P = ph.FlatPoly("compat", q, v2h)
+        if apex:
+            P.dual0_apex()
+        rcs = ph.run_sequence(P, G[name + "/in_vals"], list(G[name + "/in_ideals"]), None if init_after < 0 else init_after)
+        P.dual_adjacency()
+        can = ph.canonical(P.dump())
+        P.close()
+        g = lambda k: G[name + "/" + k]
+        gold = dict(X=g("X"), pi=g("pi"), Y=g("Y"), di=g("di"), E={tuple(e) for e in g("E")}, I={tuple(e) for e in g("I")}, DE={tuple(e) for e in g("DE")})
+        assert list(rcs) == list(g("rc")), name
+        try:
+            ph.assert_same(can, gold, rtol=0 if "snap" in fixture else tol, atol=tol)
+        except AssertionError as e:
+            raise AssertionError("%s: %s" % (name, e))
