@@ -137,7 +137,55 @@ def snap_cases():
     return cases
 
 
+def snap_dir_cases():
+    """As snap_cases, for a DIRECTION (an ideal element: alpha = 0 in poly__cut's comparisons, bslv_poly.c:596,666): halfspaces with
+    positive normals leave an unbounded polyhedron with extreme directions; the crafted cut has w.r = delta for one of them and removes a
+    neighbour of it."""
+    cases = {}
+    q, N, seed = 3, 30, 7
+    rng = np.random.default_rng(seed)
+    D = np.abs(rng.normal(size=(N, q)))
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    P = ph.FlatPoly("ref", q, 0, None)
+    ph.run_sequence(P, D, None, q + 3)
+    d = P.dump()
+    P.close()
+    pu, pi = d["pu"].astype(bool), d["pi"].astype(bool)
+    tail = np.abs(np.random.default_rng(seed + 100).normal(size=(8, q)))
+    tail = tail / np.linalg.norm(tail, axis=1, keepdims=True) * 0.97
+    for delta in (5e-10, 5e-11, 5e-12):
+        rng = np.random.default_rng(seed + 1)
+        w = None
+        for i0 in np.nonzero(pu & pi)[0]:
+            r0 = d["X"][i0]
+            nb = [b if a == i0 else a for a, b in d["E"] if i0 in (a, b)]
+            for _ in range(500):
+                w0 = rng.normal(size=q)
+                cand = w0 - ((w0 @ r0 - delta) / (r0 @ r0)) * r0
+                removes = any(pu[n] and ((pi[n] and d["X"][n] @ cand < -1e-3) or (not pi[n] and d["X"][n] @ cand < -1 - 1e-3)) for n in nb)
+                if removes and abs(cand @ r0 - delta) < 1e-15:
+                    w = cand
+                    break
+            if w is not None:
+                break
+        assert w is not None
+        cases["snapdir_q%d_delta%.0e" % (q, delta)] = (q, 0, None, False, np.vstack([D, w[None], tail]), None, q + 3)
+    return cases
+
+
 def make_poly_snap():
+    out = {}
+    for name, case in snap_dir_cases().items():
+        rcs, can = run_case("ref", case)
+        q, v2h, c, apex, vals, ideals, init_after = case
+        out[name + "/in_vals"] = np.asarray(vals, float)
+        out[name + "/in_ideals"] = np.asarray([0] * len(vals))
+        out[name + "/in_meta"] = np.array([q, v2h, int(apex), init_after])
+        out[name + "/rc"] = np.asarray(rcs)
+        for k, v in pack(can).items():
+            out[name + "/" + k] = v
+        print("poly snap (direction)", name, "primal", len(can["X"]), "dual", len(can["Y"]))
+    np.savez_compressed(os.path.join(HERE, "poly_ref_snap_dirs.npz"), **out)
     out = {}
     for name, case in snap_cases().items():
         rcs, can = run_case("ref", case)

@@ -136,3 +136,37 @@ def test_snap_band_of_poly_cut_against_the_reference(name):
         assert 1e-11 < gap < 1e-9, gap
     else:
         assert gap < 1e-13, gap
+
+
+GOLD_SD = np.load(os.path.join(HERE, "golden", "poly_ref_snap_dirs.npz"))
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in GOLD_SD.files}))
+def test_snap_band_moves_directions_too(name):
+    """The same band for an ideal element (alpha = 0 in poly__cut's comparisons, bslv_poly.c:596,666): an unbounded polyhedron, a cut
+    crafted so that w.r = delta for one of its extreme directions r while a neighbour of r is removed, eight ordinary cuts behind it
+    (tests/golden/make_golden.py snap, from the unmodified bslv_poly.c).  The polyhedron has vertices with coordinates of ~6 next to the
+    moved direction, where the reference's plain sums and the oracle's fma chains differ in the last bits: 1e-12 here, not 1e-13.
+    CPU only: the engine's k_snap treats ideal elements by the same rule but has not run this fixture on a GPU."""
+    import ctypes
+    delta = float(name.split("delta")[1])
+    q, v2h, apex, init_after = [int(x) for x in GOLD_SD[name + "/in_meta"]]
+    g = lambda k: GOLD_SD[name + "/" + k]
+    gold = dict(X=g("X"), pi=g("pi"), Y=g("Y"), di=g("di"), E={tuple(e) for e in g("E")}, I={tuple(e) for e in g("I")}, DE={tuple(e) for e in g("DE")})
+    gaps = {}
+    for snap in (1, 0):
+        P = ph.FlatPoly("oracle", q, v2h)
+        P.L.opoly_set_snap.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        P.L.opoly_snapped.argtypes = [ctypes.c_void_p]
+        P.L.opoly_snapped.restype = ctypes.c_long
+        P.L.opoly_set_snap(P.h, snap)
+        rcs = ph.run_sequence(P, g("in_vals"), list(g("in_ideals")), init_after)
+        P.dual_adjacency()
+        can, moved = ph.canonical(P.dump()), P.L.opoly_snapped(P.h)
+        P.close()
+        assert list(rcs) == list(g("rc"))
+        assert moved == (1 if snap and delta > 1e-11 else 0)
+        ph.assert_same(can, gold, rtol=1e-12 if snap else 1e-8, atol=1e-12 if snap else 1e-8)
+        gaps[snap] = (np.abs(can["X"] - gold["X"]) / (1.0 + np.abs(gold["X"]))).max()        # (far vertices of an unbounded polyhedron: relative)
+    if delta > 1e-11:
+        assert gaps[0] > 10 * gaps[1] and gaps[0] > 1e-11, gaps
