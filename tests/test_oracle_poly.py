@@ -147,7 +147,7 @@ def test_snap_band_moves_directions_too(name):
     crafted so that w.r = delta for one of its extreme directions r while a neighbour of r is removed, eight ordinary cuts behind it
     (tests/golden/make_golden.py snap, from the unmodified bslv_poly.c).  The polyhedron has vertices with coordinates of ~6 next to the
     moved direction, where the reference's plain sums and the oracle's fma chains differ in the last bits: 1e-12 here, not 1e-13.
-    CPU only: the engine's k_snap treats ideal elements by the same rule but has not run this fixture on a GPU."""
+    The engine runs the same fixture in tests/test_poly_gpu.py::test_snap_band_moves_a_direction_as_the_reference_does."""
     import ctypes
     delta = float(name.split("delta")[1])
     q, v2h, apex, init_after = [int(x) for x in GOLD_SD[name + "/in_meta"]]

@@ -402,3 +402,37 @@ def test_snap_band_of_poly_cut_matches_the_reference_when_switched_on():
                 if snap or not batched:           # (the default's batched form = rounds of independent cuts: same sets, other slot numbers)
                     assert_slotwise_equal(do, dg)
                 ph.assert_same(ph.canonical(dg), gold, rtol=0, atol=1e-12 if snap else 1e-9)
+
+
+def test_snap_band_moves_a_direction_as_the_reference_does():
+    """The band for an ideal element (alpha = 0, bslv_poly.c:596,666): tests/golden/poly_ref_snap_dirs.npz, an extreme direction of an
+    unbounded polyhedron with w.r = 5e-10 / 5e-11 / 5e-12 for the crafted cut w.  Engine with the switch on against the oracle's
+    restatement slot for slot and against the reference's fixture (relative 1e-12: far vertices)."""
+    import ctypes
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poly_ref_snap_dirs.npz"))
+    for name in sorted({k.split("/")[0] for k in G.files}):
+        q, v2h, apex, init_after = [int(x) for x in G[name + "/in_meta"]]
+        vals = G[name + "/in_vals"]
+        g = lambda k: G[name + "/" + k]
+        gold = dict(X=g("X"), pi=g("pi"), Y=g("Y"), di=g("di"), E={tuple(e) for e in g("E")}, I={tuple(e) for e in g("I")}, DE={tuple(e) for e in g("DE")})
+        O = ph.FlatPoly("oracle", q, v2h)
+        O.L.opoly_set_snap.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        O.L.opoly_snapped.argtypes = [ctypes.c_void_p]
+        O.L.opoly_snapped.restype = ctypes.c_long
+        O.L.opoly_set_snap(O.h, 1)
+        rco = ph.run_sequence(O, vals, None, init_after)
+        O.dual_adjacency()
+        do, moved_o = O.dump(), O.L.opoly_snapped(O.h)
+        O.close()
+        E = PolyEngine(q, v2h, None)
+        E.set_batch_mode(0)
+        E.set_snap(1)
+        rcg = ph.run_sequence(E, vals, None, init_after)
+        E.dual_adjacency()
+        dg, moved_g = E.dump(), E.snapped()
+        E.close()
+        assert list(rcg) == list(rco) == list(g("rc")), name
+        assert moved_g == moved_o == (1 if float(name.split("delta")[1]) > 1e-11 else 0), name
+        assert_slotwise_equal(do, dg)
+        ph.assert_same(ph.canonical(dg), gold, rtol=1e-12, atol=1e-12)
